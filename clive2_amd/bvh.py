@@ -1,0 +1,176 @@
+"""Host BVH: top-down full-sweep SAH object split, BFS flattening.
+
+Produces the reference's flattened convention (`src/bvh.py:329-389`):
+`Box.right == 0` -> inner node with children at `left`, `left+1`; otherwise a leaf holding
+triangles `[left, right)` of the leaf-ordered `Triangle[]`.  The split rule reproduces the
+reference's `object_split` (`src/bvh.py:132-191`) decision for decision -- including its cost
+`A_left(k+1 tris) * k + A_right * (n-1-k)` (left count short by one), first-minimum
+tie-breaking and the pending-stack "depth" limit of `construct_BVH` (`:288-313`) -- so that
+identical inputs give the identical tree; `tests/test_scene_bvh.py` pins this against arrays
+captured from the reference.  (Image parity does not depend on the tree shape, only this
+module's fixture parity does.)
+
+Design: one set of per-triangle arrays for the whole scene plus an index vector per node;
+nodes are rows of parallel lists, not objects.
+"""
+import numpy as np
+
+from .constants import INF, NEG_INF, MAX_MEMBERS, MAX_DEPTH
+from . import struct_types
+
+_FIELDS = ("faces", "triangles", "mins", "maxes", "face_normals", "smoothed_normals",
+           "surface_areas", "material", "emitter", "camera")
+
+
+class FastTreeBox:
+    """A triangle soup (and, after `construct_BVH`, the root of a tree over it)."""
+
+    def __init__(self, faces, triangles, mins, maxes, face_normals, smoothed_normals,
+                 surface_areas, material, emitter, camera):
+        self.faces, self.triangles = faces, triangles
+        self.mins, self.maxes = mins, maxes
+        self.face_normals, self.smoothed_normals = face_normals, smoothed_normals
+        self.surface_areas, self.material = surface_areas, material
+        self.emitter, self.camera = emitter, camera
+        self.min = mins.min(axis=0) if len(mins) else INF
+        self.max = maxes.max(axis=0) if len(maxes) else NEG_INF
+        self.tree = None          # filled by construct_BVH
+
+    def __len__(self):
+        return len(self.triangles)
+
+    @classmethod
+    def empty_box(cls):
+        f32 = np.float32
+        return cls(np.empty((0, 3), np.uint32), np.empty((0, 3, 3), f32), np.empty((0, 3), f32),
+                   np.empty((0, 3), f32), np.empty((0, 3), f32), np.empty((0, 3, 3), f32),
+                   np.empty((0,), f32), np.empty((0,), np.int32), np.empty((0,), np.bool_),
+                   np.empty((0,), np.bool_))
+
+    @classmethod
+    def from_triangle_objects(cls, objs):
+        """float32 soup from hand-placed triangles (reference: bvh.py:53-83)."""
+        tri = np.array([[t.v0, t.v1, t.v2] for t in objs], dtype=np.float32)
+        flat_n = np.array([t.n for t in objs], dtype=np.float32)
+        return cls(
+            faces=np.zeros((len(objs), 3), dtype=np.uint32), triangles=tri,
+            mins=tri.min(axis=1), maxes=tri.max(axis=1), face_normals=flat_n,
+            smoothed_normals=np.repeat(flat_n[:, None, :], 3, axis=1),
+            surface_areas=np.array([t.surface_area for t in objs], dtype=np.float32),
+            material=np.array([t.material for t in objs], dtype=np.int32),
+            emitter=np.array([t.emitter for t in objs], dtype=np.bool_),
+            camera=np.array([t.camera for t in objs], dtype=np.bool_))
+
+    def __add__(self, other):
+        if not isinstance(other, FastTreeBox):
+            raise TypeError("Can only add another FastTreeBox")
+        return FastTreeBox(*(np.concatenate((getattr(self, f), getattr(other, f)), axis=0)
+                             for f in _FIELDS))
+
+
+def surface_areas(mins, maxes):
+    d = maxes - mins
+    return 2 * (d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0])
+
+
+def surface_area(lo, hi):
+    d = hi - lo
+    return 2 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0])
+
+
+def _sweep_split(mins, maxes):
+    """Best (cost, order, left_count) over the three centroid-sorted sweeps."""
+    centers = (mins + maxes) / 2
+    n = len(mins)
+    k = np.arange(n - 1)
+    best = (np.inf, None, 0)
+    for axis in range(3):
+        order = np.argsort(centers[:, axis])
+        lo, hi = mins[order], maxes[order]
+        area_l = surface_areas(np.minimum.accumulate(lo), np.maximum.accumulate(hi))[:-1]
+        area_r = surface_areas(np.minimum.accumulate(lo[::-1])[::-1],
+                               np.maximum.accumulate(hi[::-1])[::-1])[1:]
+        cost = area_l * k + area_r * ((n - 1) - k)
+        j = int(np.argmin(cost))
+        if cost[j] < best[0]:
+            best = (cost[j], order, j + 1)
+    return best
+
+
+class _Tree:
+    """Parallel-list binary tree over index vectors into one soup."""
+
+    def __init__(self, soup):
+        self.soup = soup
+        self.members = [np.arange(len(soup))]    # per node: triangle ids, in sweep order
+        self.kids = [None]                       # per node: (left, right) node ids or None
+
+    def split(self, node):
+        ids = self.members[node]
+        _, order, n_left = _sweep_split(self.soup.mins[ids], self.soup.maxes[ids])
+        l, r = len(self.members), len(self.members) + 1
+        self.members += [ids[order[:n_left]], ids[order[n_left:]]]
+        self.kids += [None, None]
+        self.kids[node] = (l, r)
+        return l, r
+
+
+def construct_BVH(root_box):
+    """Grow the tree in the reference's order: LIFO work list, right child pushed first,
+    and a node becomes a leaf when it has <= MAX_MEMBERS triangles or when MORE than
+    MAX_DEPTH nodes are still pending (bvh.py:292-295).  Returns `root_box` with `.tree`."""
+    tree = _Tree(root_box)
+    pending = [0]
+    deepest = 0
+    while pending:
+        node = pending.pop()
+        deepest = max(deepest, len(pending))
+        if len(tree.members[node]) <= MAX_MEMBERS or len(pending) > MAX_DEPTH:
+            continue
+        l, r = tree.split(node)
+        pending += [r, l]
+    tree.max_pending = deepest
+    root_box.tree = tree
+    return root_box
+
+
+def count_boxes(root):
+    return len(root.tree.members) if root.tree is not None else 1
+
+
+def np_flatten_bvh(root):
+    """Breadth-first numbering -> (Box[], Triangle[]) in the reference layout."""
+    tree = root.tree if root.tree is not None else _Tree(root)
+    soup = tree.soup
+    n_nodes = len(tree.members)
+    boxes = np.zeros(n_nodes, dtype=struct_types.Box)
+    bfs = [0]
+    head = 0
+    leaf_chunks = []
+    n_tri = 0
+    while head < len(bfs):
+        node = bfs[head]
+        ids = tree.members[node]
+        boxes["min"][head, :3] = soup.mins[ids].min(axis=0)
+        boxes["max"][head, :3] = soup.maxes[ids].max(axis=0)
+        if tree.kids[node] is not None:
+            boxes["left"][head] = len(bfs)        # children land at the queue tail
+            bfs += list(tree.kids[node])
+        else:
+            boxes["left"][head], boxes["right"][head] = n_tri, n_tri + len(ids)
+            n_tri += len(ids)
+            leaf_chunks.append(ids)
+        head += 1
+    perm = np.concatenate(leaf_chunks) if leaf_chunks else np.zeros(0, dtype=np.int64)
+    assert head == n_nodes and n_tri == len(soup) == len(perm)
+
+    tris = np.zeros(n_tri, dtype=struct_types.Triangle)
+    for k, name in enumerate(("v0", "v1", "v2")):
+        tris[name][:, :3] = soup.triangles[perm, k]
+    for k, name in enumerate(("n0", "n1", "n2")):
+        tris[name][:, :3] = soup.smoothed_normals[perm, k]
+    tris["normal"][:, :3] = soup.face_normals[perm]
+    tris["material"] = soup.material[perm]
+    tris["is_light"] = soup.emitter[perm]
+    tris["is_camera"] = soup.camera[perm]
+    return boxes, tris

@@ -1,0 +1,145 @@
+"""Generate golden fixtures from the reference's HOST-side Python (scene/BVH/camera plumbing).
+
+Runs ONLY in the authoring container (needs /root/reference, which never travels to the
+GPU box).  The device code of the reference (trace.metal) cannot run anywhere in this
+pipeline, so these fixtures pin SURVEY.md §8 row a21 only (scene -> Box[]/Triangle[]/
+Material[]/Camera[] arrays).  The reference modules are imported unmodified; the four
+third-party modules they import that are absent here are replaced by inert in-memory
+stand-ins (numba.njit = identity, metalcompute.Device.buffer(x) = x; objloader/plyfile
+are never called).  Output: small .npz files with raw struct bytes.
+
+    python tests/golden/make_fixtures.py
+"""
+import io
+import os
+import sys
+import types
+import contextlib
+
+import numpy as np
+
+REF = "/root/reference/src"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_stand_ins():
+    numba = types.ModuleType("numba")
+    numba.njit = lambda f=None, **kw: f if f is not None else (lambda g: g)
+    sys.modules["numba"] = numba
+    sys.modules["objloader"] = types.ModuleType("objloader")
+    ply = types.ModuleType("plyfile")
+    ply.PlyData = object
+    sys.modules["plyfile"] = ply
+    mc = types.ModuleType("metalcompute")
+
+    class Device:
+        def buffer(self, x):
+            return x
+
+    mc.Device = Device
+    mc.release = lambda *_a, **_k: None
+    mc.error = RuntimeError
+    sys.modules["metalcompute"] = mc
+
+
+def _raw(a):
+    a = np.ascontiguousarray(a)
+    return np.frombuffer(a.tobytes(), dtype=np.uint8).copy()
+
+
+def scene_fixture(ref_scene, w, h):
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = ref_scene.create_scene_from_preset("empty", w, h)
+    out = dict(
+        boxes=_raw(s.boxes), triangles=_raw(s.triangles), materials=_raw(s.materials),
+        camera=_raw(s.camera), light_triangles=_raw(s.light_triangles),
+        light_surface_areas=np.asarray(s.light_surface_areas, dtype=np.float32),
+        light_triangle_indices=np.asarray(s.light_triangle_indices, dtype=np.int32),
+        camera_triangle_indices=np.asarray(s.camera_triangle_indices, dtype=np.int32),
+        light_counts=np.asarray(s.light_counts, dtype=np.int32).reshape(1),
+        n_boxes=np.int32(len(s.boxes)), n_triangles=np.int32(len(s.triangles)),
+    )
+    s.__class__.__del__ = lambda self: None
+    return out
+
+
+def icosphere(subdiv):
+    """Deterministic icosphere (unit radius): the same generator the package ships."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t),
+         (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4),
+         (11, 10, 2), (10, 7, 6), (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8),
+         (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [np.array(p, dtype=np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(subdiv):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[k] = len(v) - 1
+            return cache[k]
+
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.array(v, dtype=np.float64), np.array(f, dtype=np.int32)
+
+
+def mesh_fixture(ref_scene, ref_load, ref_bvh, ref_camera, subdiv, w, h):
+    """Cornell box + one smooth-shaded icosphere pushed through the reference's
+    fast_load -> construct_BVH -> np_flatten_bvh chain (scene.py:41-71)."""
+    verts, faces = icosphere(subdiv)
+    verts = verts * 2.0 + np.array([0.0, 1.0, 0.0])
+    with contextlib.redirect_stdout(io.StringIO()):
+        cam = ref_camera.Camera(center=np.array([0, 1.5, 6]), direction=np.array([0, 0, -1]),
+                                pixel_width=w, pixel_height=h, phys_width=w / h, phys_height=1)
+        tris = list(ref_load.camera_geometry(cam)) + list(ref_load.triangles_for_box())
+        box = ref_bvh.FastTreeBox.from_triangle_objects(tris)
+        box = box + ref_load.fast_load(verts, faces, material=5)
+        bvh = ref_bvh.construct_BVH(box)
+        np_boxes, np_tris = ref_bvh.np_flatten_bvh(bvh)
+    return dict(vertices=verts, faces=faces, boxes=_raw(np_boxes), triangles=_raw(np_tris),
+                n_boxes=np.int32(len(np_boxes)), n_triangles=np.int32(len(np_tris)))
+
+
+def main():
+    _install_stand_ins()
+    sys.path.insert(0, REF)
+    import scene as ref_scene
+    import load as ref_load
+    import bvh as ref_bvh
+    import camera as ref_camera
+    import struct_types as ref_st
+
+    sizes = {n: np.int32(getattr(ref_st, n).itemsize)
+             for n in ("Ray", "Path", "Box", "Triangle", "Material", "Camera")}
+    offsets = {}
+    for n in ("Ray", "Path", "Box", "Triangle", "Material", "Camera"):
+        dt = getattr(ref_st, n)
+        for fname in dt.names:
+            offsets[f"{n}.{fname}"] = np.int32(dt.fields[fname][1])
+    np.savez_compressed(os.path.join(OUT, "struct_layout.npz"), **sizes, **offsets)
+
+    for (w, h) in ((256, 256), (1920, 1080), (64, 48)):
+        np.savez_compressed(os.path.join(OUT, f"cornell_{w}x{h}.npz"), **scene_fixture(ref_scene, w, h))
+
+    for subdiv in (1, 2):
+        np.savez_compressed(os.path.join(OUT, f"cornell_icosphere{subdiv}_64x48.npz"),
+                            **mesh_fixture(ref_scene, ref_load, ref_bvh, ref_camera, subdiv, 64, 48))
+
+    # tone_map (camera.py:73-82) on a small seeded image: output-stage fixture
+    rng = np.random.RandomState(7)
+    img = rng.rand(12, 16, 3).astype(np.float32) * 3.0
+    with contextlib.redirect_stdout(io.StringIO()):
+        tm = ref_camera.tone_map(img, exposure=4.0)
+    np.savez_compressed(os.path.join(OUT, "tone_map.npz"), image=img, out=tm)
+    print("fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
