@@ -1,0 +1,108 @@
+// bvh_traverse.hpp -- closest-hit BVH query, stackless, with the top of the tree staged in LDS.
+//
+// Reference semantics (`src/trace.metal:106-176`): slab box test that returns the entry distance,
+// Moller-Trumbore triangle test (reject t <= DELTA, inclusive u,v bounds, no parallel-ray guard),
+// depth-first walk that visits the RIGHT child (left+1) before the left one, prunes a node when
+// its entry distance is not < best_t, scans leaf triangles in ascending order and keeps a hit
+// only on strict t < best_t.
+//
+// MI355X formulation: the reference's 64-entry per-thread stack would live in scratch memory.
+// Instead every node carries a SKIP link (the node the reference's stack would pop next if this
+// subtree were abandoned), computed once at scene upload.  Walking "hit inner -> left+1, else
+// -> skip" visits exactly the nodes the stack version visits, in the same order, testing each
+// against the same best_t -- so hits (including exact-t ties) are identical -- with no stack
+// and no scratch traffic.  Nodes [0, n_lds_nodes) (breadth-first = the top levels) and, when
+// they fit, all intersection triangles are copied into LDS by each workgroup.
+//
+// Device layouts (built by Renderer::upload_scene):
+//   node   : float4 lo = {min.xyz, as_float(left)}, float4 hi = {max.xyz, as_float(right)}  (32 B)
+//            right == 0 -> inner (children left, left+1); else leaf over triangles [left, right)
+//   skip   : int32 per node, -1 terminates
+//   tri    : 3 x float4 = {v0.xyz,-}, {e1.xyz,-}, {e2.xyz,-} with e1 = v1-v0, e2 = v2-v0 (the same
+//            float32 subtractions the reference performs per test, done once)
+#pragma once
+#include "vecmath.hpp"
+#include "bsdf.hpp"
+
+namespace cl2 {
+
+struct BvhView {
+    const float4* nodes;     // 2 float4 per node
+    const int* skip;
+    const float4* tris;      // 3 float4 per triangle
+    int n_nodes;
+    int n_tris;
+    int n_lds_nodes;         // nodes staged in LDS (<= LDS_NODE_CAP)
+    int lds_tris;            // 1: all triangles staged in LDS (n_tris <= LDS_TRI_CAP)
+};
+
+constexpr int LDS_NODE_CAP = 256;   // 256 * (32 + 4) B = 9 KB
+constexpr int LDS_TRI_CAP = 128;    // 128 * 48 B = 6 KB
+
+struct BvhLds {
+    float4 nodes[2 * LDS_NODE_CAP];
+    float4 tris[3 * LDS_TRI_CAP];
+    int skip[LDS_NODE_CAP];
+};
+
+// Cooperative copy of the staged part of the tree; every thread of the block must call it.
+__device__ __forceinline__ void stage_bvh(BvhLds& s, const BvhView& b) {
+    const int nt = blockDim.x, t = threadIdx.x;
+    for (int i = t; i < 2 * b.n_lds_nodes; i += nt) s.nodes[i] = b.nodes[i];
+    for (int i = t; i < b.n_lds_nodes; i += nt) s.skip[i] = b.skip[i];
+    if (b.lds_tris)
+        for (int i = t; i < 3 * b.n_tris; i += nt) s.tris[i] = b.tris[i];
+    __syncthreads();
+}
+
+struct Hit { int tri; float t, u, v; };
+
+// Closest hit along (o, d) with inv = 1/d.  COUNT adds node/triangle test tallies.
+template <bool COUNT>
+__device__ __forceinline__ Hit closest_hit(const BvhLds& s, const BvhView& b, V3 o, V3 d, V3 inv,
+                                          unsigned& n_box, unsigned& n_tri) {
+    Hit best{-1, __builtin_inff(), 0.0f, 0.0f};
+    int node = 0;
+    while (node >= 0) {
+        float4 lo, hi;
+        int next;
+        if (node < b.n_lds_nodes) { lo = s.nodes[2 * node]; hi = s.nodes[2 * node + 1]; next = s.skip[node]; }
+        else { lo = b.nodes[2 * node]; hi = b.nodes[2 * node + 1]; next = b.skip[node]; }
+        if (COUNT) n_box++;
+        // ray_box_intersect, trace.metal:106-115 (called with t = INFINITY, :153-155)
+        float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
+        float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
+        float tmin = max_msl(max_msl(min_msl(t0x, t1x), min_msl(t0y, t1y)), max_msl(min_msl(t0z, t1z), 0.0f));
+        float tmax = min_msl(min_msl(max_msl(t0x, t1x), max_msl(t0y, t1y)), min_msl(max_msl(t0z, t1z), __builtin_inff()));
+        if (tmin <= tmax && tmin < best.t) {
+            const int left = __float_as_int(lo.w), right = __float_as_int(hi.w);
+            if (right == 0) {
+                next = left + 1;                       // right child first (trace.metal:158-159)
+            } else {
+                for (int i = left; i < right; i++) {   // trace.metal:161-172
+                    float4 a0, a1, a2;
+                    if (b.lds_tris) { a0 = s.tris[3 * i]; a1 = s.tris[3 * i + 1]; a2 = s.tris[3 * i + 2]; }
+                    else { a0 = b.tris[3 * i]; a1 = b.tris[3 * i + 1]; a2 = b.tris[3 * i + 2]; }
+                    if (COUNT) n_tri++;
+                    // ray_triangle_intersect, trace.metal:117-142
+                    V3 e1 = v3(a1), e2 = v3(a2);
+                    V3 h = cross(d, e2);
+                    float a = dot(e1, h);
+                    float f = 1.0f / a;
+                    V3 sv = o - v3(a0);
+                    float u = f * dot(sv, h);
+                    if (u < 0 || u > 1) continue;
+                    V3 q = cross(sv, e1);
+                    float v = f * dot(d, q);
+                    if (v < 0 || u + v > 1) continue;
+                    float t = f * dot(e2, q);
+                    if (t > DELTA_F && t < best.t) { best.tri = i; best.t = t; best.u = u; best.v = v; }
+                }
+            }
+        }
+        node = next;
+    }
+    return best;
+}
+
+}  // namespace cl2

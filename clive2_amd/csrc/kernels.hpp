@@ -1,0 +1,761 @@
+// kernels.hpp -- wavefront bidirectional path tracing kernels for gfx950 (MI355X).
+//
+// The reference runs the per-sample pipeline as two megakernels (`generate_paths`,
+// `connect_paths`, src/trace.metal:381-532, :620-869) that keep whole 1040-byte Path records in
+// thread-private memory, followed by a 300-launch bitonic sort + host bincount to splat the light
+// image.  Here the same arithmetic is a WAVEFRONT pipeline over SoA state:
+//
+//   gen_light_rays / gen_camera_rays         vertex slot 0 of each subpath        (K1, K2)
+//   6 x { traverse_paths ; bounce }          per subpath kind; survivors are compacted into the
+//                                            next level's queue with wave ballots  (K3)
+//   connect_setup                            enumerate (t,s) strategy pairs, cull, emit a compacted
+//                                            queue of connection rays             (K5, first half)
+//   traverse_conn                            closest hit for every connection ray
+//   connect_resolve                          MIS weights + contributions per pixel in the
+//                                            reference's (t,s) order; t=1 splats by float atomics
+//                                            (replaces K4, K7 x300, host bincount, K8)
+//   finalize / accumulate                    3x3 reconstruction filter, on-device accumulators (K6,
+//                                            renderer.py:253-278)
+//
+// Path-vertex SoA (per subpath kind, slot v in [0,6), pixel p; index v*B + p):
+//   P0 = {origin.xyz, c_importance}  P1 = {direction.xyz, l_importance}
+//   P2 = {normal.xyz, meta}          P3 = {color.xyz, tot_importance}     tri = triangle index
+//   meta = material | hit_light<<8 | hit_camera<<9
+// Every arithmetic statement follows the cited reference lines in the same operation order
+// (IEEE binary32, -ffp-contract=off), so per-stage results can be compared exactly with a CPU
+// evaluation of the same statements.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "vecmath.hpp"
+#include "detmath.hpp"
+#include "bsdf.hpp"
+#include "bvh_traverse.hpp"
+
+namespace cl2 {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES_PER_BLOCK = BLOCK / 64;
+constexpr int MAX_VERTS = 6;          // bounce loop bound, trace.metal:407
+constexpr int CONN_SLOTS = 36;        // (t in 1..6) x (s in 1..6) strategy pairs that need a ray
+constexpr int TAG_PID_BITS = 26;
+constexpr int META_HIT_LIGHT = 1 << 8;
+constexpr int META_HIT_CAMERA = 1 << 9;
+
+struct CameraRec {   // byte-identical to struct Camera, trace.metal:72-85
+    float center[4], focal_point[4], direction[4], dx[4], dy[4];
+    int pixel_width, pixel_height;
+    float phys_width, phys_height, h_fov, v_fov;
+    int pad[2];
+};
+
+struct MaterialDev { float4 color_type; float4 emission_alpha; float ior; float pad[3]; };  // 48 B
+
+struct PathBufs {
+    float4 *P0, *P1, *P2, *P3;
+    int* tri;
+    int* len;
+    float* carry;
+};
+
+struct Stats {   // device-side tallies
+    unsigned long long rays, box_tests, tri_tests, conn_rays, counted_rays;
+};
+
+__device__ __forceinline__ V3 cam3(const float* p) { return v3(p[0], p[1], p[2]); }
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// Block-level stream compaction: wave ballots + one global atomic per block.
+// Returns the output index for threads with `pred`, garbage otherwise.  All threads must call.
+__device__ __forceinline__ unsigned block_compact_index(bool pred, unsigned* counter) {
+    __shared__ unsigned s_wave_total[WAVES_PER_BLOCK];
+    __shared__ unsigned s_base;
+    const unsigned long long mask = __ballot(pred);
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const unsigned before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave_total[wave] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int w = 0; w < WAVES_PER_BLOCK; w++) tot += s_wave_total[w];
+        s_base = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    unsigned off = s_base + before;
+    for (int w = 0; w < wave; w++) off += s_wave_total[w];
+    return off;
+}
+
+// ---------------------------------------------------------------- K1: generate_light_rays
+// trace.metal:1070-1124.  Writes vertex slot 0 of the light subpath.
+__global__ __launch_bounds__(BLOCK) void k_gen_light_rays(
+        int B, const float4* __restrict__ light_tris /*5 float4 per light: v0, v1, v2, normal, {material}*/,
+        const float* __restrict__ light_areas, const int* __restrict__ light_tri_index,
+        const MaterialDev* __restrict__ mats, int light_count, uint2* __restrict__ seeds, PathBufs pb) {
+    const int id = blockIdx.x * BLOCK + threadIdx.x;
+    if (id >= B) return;
+    uint2 sd = seeds[id];
+    uint32_t seed0 = sd.x, seed1 = sd.y;
+    int li = (int)(xorshift_random(seed0) * light_count);
+    if (li > light_count - 1) li = light_count - 1;     // the draw can be exactly 1.0
+    const float4 a0 = light_tris[5 * li], a1 = light_tris[5 * li + 1], a2 = light_tris[5 * li + 2],
+                 an = light_tris[5 * li + 3], am = light_tris[5 * li + 4];
+    const float area = light_areas[li];
+    float u = xorshift_random(seed0);
+    float v = xorshift_random(seed1);
+    if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+    const float w = 1.0f - u - v;
+    const V3 normal = v3(an);
+    const V3 origin = ((v3(a0) * u + v3(a1) * v) + v3(a2) * w) + DELTA_F * normal;
+    V3 x, y;
+    orthonormal(normal, x, y);
+    const float rx = xorshift_random(seed0);
+    const float ry = xorshift_random(seed1);
+    const V3 dir = random_hemisphere_uniform(x, y, normal, rx, ry);
+    const int material = __float_as_int(am.x);
+    const float4 em = mats[material].emission_alpha;
+    const float l_imp = 1.0f / (light_count * area);
+    pb.P0[id] = f4(origin, 1.0f);                 // c_importance "filled in later"
+    pb.P1[id] = f4(dir, l_imp);
+    pb.P2[id] = f4(normal, __int_as_float(material));
+    pb.P3[id] = make_float4(em.x, em.y, em.z, l_imp);
+    pb.tri[id] = light_tri_index[li];
+    pb.len[id] = 0;
+    pb.carry[id] = 1.0f / (2.0f * PI_F);          // new_ray.l_importance, trace.metal:401
+    seeds[id] = make_uint2(seed0, seed1);
+}
+
+// ---------------------------------------------------------------- K2: generate_camera_rays
+// trace.metal:1020-1067 with indices[id] == id (renderer.py:92-94).
+__global__ __launch_bounds__(BLOCK) void k_gen_camera_rays(int B, CameraRec c, uint2* __restrict__ seeds, PathBufs pb) {
+    const int id = blockIdx.x * BLOCK + threadIdx.x;
+    if (id >= B) return;
+    uint2 sd = seeds[id];
+    uint32_t seed0 = sd.x, seed1 = sd.y;
+    const float x_offset = xorshift_random(seed0);
+    const float y_offset = xorshift_random(seed1);
+    const int pixel_x = id % c.pixel_width, pixel_y = id / c.pixel_width;
+    const float xn = (pixel_x + x_offset - 0.5f * c.pixel_width) / (float)c.pixel_width;
+    const float yn = (pixel_y + y_offset - 0.5f * c.pixel_height) / (float)c.pixel_height;
+    const V3 xv = (xn * cam3(c.dx)) * c.phys_width;
+    const V3 yv = (yn * cam3(c.dy)) * c.phys_height;
+    const V3 origin = (cam3(c.center) + xv) + yv;
+    const V3 dir = normalize(cam3(c.focal_point) - origin);
+    const float c_imp = 1.0f / (c.phys_width * c.phys_height);
+    pb.P0[id] = f4(origin, c_imp);
+    pb.P1[id] = f4(dir, 1.0f);                    // l_importance "filled in later"
+    pb.P2[id] = f4(cam3(c.direction), __int_as_float(7));
+    pb.P3[id] = make_float4(1.0f, 1.0f, 1.0f, c_imp);
+    pb.tri[id] = -1;
+    pb.len[id] = 0;
+    pb.carry[id] = c_imp;                         // new_ray.c_importance, trace.metal:404
+    seeds[id] = make_uint2(seed0, seed1);
+}
+
+// ---------------------------------------------------------------- traversal of subpath rays
+// One closest-hit query (trace.metal:144-176) per queued path; ray = (P0.xyz, P1.xyz) of `level`.
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_traverse_paths(
+        BvhView bvh, const int* __restrict__ queue, const unsigned* __restrict__ count,
+        const float4* __restrict__ P0v, const float4* __restrict__ P1v, float4* __restrict__ hit, Stats* stats) {
+    __shared__ BvhLds lds;
+    stage_bvh(lds, bvh);
+    const unsigned n = *count;
+    const unsigned j = blockIdx.x * BLOCK + threadIdx.x;
+    unsigned nb = 0, nt = 0;
+    if (j < n) {
+        const int pid = queue ? queue[j] : (int)j;
+        const V3 o = v3(P0v[pid]), d = v3(P1v[pid]);
+        const Hit h = closest_hit<COUNT>(lds, bvh, o, d, rcp3(d), nb, nt);
+        hit[pid] = make_float4(__int_as_float(h.tri), h.t, h.u, h.v);
+    }
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) { nb += __shfl_down(nb, off); nt += __shfl_down(nt, off); }
+        if (lane_id() == 0) {
+            atomicAdd(&stats->box_tests, (unsigned long long)nb);
+            atomicAdd(&stats->tri_tests, (unsigned long long)nt);
+        }
+    }
+    if (j == 0) {
+        atomicAdd(&stats->rays, (unsigned long long)n);
+        if (COUNT) atomicAdd(&stats->counted_rays, (unsigned long long)n);
+    }
+}
+
+// ---------------------------------------------------------------- K3 body: one bounce
+// trace.metal:417-516 for iteration `level` of the path loop.  `carry` holds new_ray's forward
+// importance (set by the previous iteration through next_ray, or by the generators).
+template <bool FROM_CAMERA>
+__global__ __launch_bounds__(BLOCK) void k_bounce(
+        int level, int last, const int* __restrict__ queue_in, const unsigned* __restrict__ count_in,
+        int* __restrict__ queue_out, unsigned* __restrict__ count_out, int B, PathBufs pb,
+        const float4* __restrict__ hit, uint2* __restrict__ seeds,
+        const float4* __restrict__ tri_shade, const MaterialDev* __restrict__ mats) {
+    const unsigned n = *count_in;
+    const unsigned j = blockIdx.x * BLOCK + threadIdx.x;
+    bool alive = false;
+    int pid = 0;
+    if (j < n) {
+        pid = queue_in ? queue_in[j] : (int)j;
+        const float4 h = hit[pid];
+        const int best_i = __float_as_int(h.x);
+        if (best_i != -1) {
+            const size_t cur = (size_t)level * B + pid;
+            float4 p0 = pb.P0[cur], p1 = pb.P1[cur];
+            const float4 p3 = pb.P3[cur];
+            const float best_t = h.y, u = h.z, v = h.w;
+            const float4 s0 = tri_shade[4 * best_i], s1 = tri_shade[4 * best_i + 1],
+                         s2 = tri_shade[4 * best_i + 2], s3 = tri_shade[4 * best_i + 3];
+            const int material = __float_as_int(s0.w);
+            const bool is_light = __float_as_int(s1.w) != 0, is_camera = __float_as_int(s2.w) != 0;
+            const MaterialDev mat = mats[material];
+            const int mtype = __float_as_int(mat.color_type.w);
+            const float alpha = mat.emission_alpha.w;
+            const V3 tn = v3(s3), rd = v3(p1), ro = v3(p0), rcol = v3(p3);
+
+            const V3 sn = normalize((v3(s0) * (1 - u - v) + v3(s1) * u) + v3(s2) * v);   // sample_normal :330-332
+            const float facing = dot(-rd, tn);
+            V3 nrm = sn;
+            float ni = 1.0f, no = mat.ior;
+            bool ok = true;
+            if (facing > 0) { }
+            else if (facing < 0) { nrm = -sn; ni = mat.ior; no = 1.0f; }
+            else ok = false;                                                           // :433-435
+            if (ok) {
+                const V3 new_origin = ro + rd * best_t;
+                const bool hit_light = is_light && dot(rd, tn) < 0.0f;
+                const V3 wi = -rd;
+                uint2 sd = seeds[pid];
+                const float rxa = xorshift_random(sd.x);
+                const float rya = xorshift_random(sd.y);
+                const float rxb = xorshift_random(sd.x);
+                const float ryb = xorshift_random(sd.y);
+                seeds[pid] = sd;
+
+                const V3 m = GGX_sample(nrm, rxa, rya, alpha);
+                if (!(dot(wi, m) < 0.0f) && !(dot(m, nrm) < 0.0f)) {
+                    const float fresnel = degreve_fresnel(wi, m, ni, no);
+                    Bounce b;
+                    if (mtype == 0) b = diffuse_bounce(wi, nrm, FROM_CAMERA, rxb, ryb);
+                    else if (mtype == 1) {
+                        if (rxb <= fresnel) b = reflect_bounce(wi, nrm, m, ni, no, alpha, FROM_CAMERA);
+                        else b = transmit_bounce(wi, nrm, m, ni, no, alpha, FROM_CAMERA);
+                    } else if (mtype == 2) {
+                        if (rxb <= fresnel) b = reflect_bounce(wi, nrm, m, ni, no, alpha, FROM_CAMERA);
+                        else b = diffuse_bounce(wi, nrm, FROM_CAMERA, rxb, ryb);
+                    } else b = reflect_bounce(wi, nrm, m, ni, no, alpha, FROM_CAMERA);
+
+                    const float wi_n = dot(wi, tn), wo_n = dot(b.wo, tn);
+                    V3 ncol = b.f * rcol;
+                    if ((wi_n > 0.0f && wo_n > 0.0f) || (wi_n < 0.0f && wo_n > 0.0f)) ncol = ncol * v3(mat.color_type);
+
+                    const float fwd = pb.carry[pid];            // new_ray.{c,l}_importance
+                    const float new_tot = p3.w * fwd;           // :502 / :506
+                    if (!(b.f == 0.0f)) {                       // :509
+                        // path.rays[level] = ray, with its reverse pdf now known (:501 / :505)
+                        if (FROM_CAMERA) { p1.w = b.l_p; pb.P1[cur] = p1; }
+                        else { p0.w = b.c_p; pb.P0[cur] = p0; }
+                        pb.len[pid] = level + 1;
+                        if (!last) {
+                            const size_t nxt = cur + B;
+                            const int meta = material | (hit_light ? META_HIT_LIGHT : 0) | (is_camera ? META_HIT_CAMERA : 0);
+                            pb.P0[nxt] = f4(new_origin, FROM_CAMERA ? fwd : 0.0f);
+                            pb.P1[nxt] = f4(b.wo, FROM_CAMERA ? 0.0f : fwd);
+                            pb.P2[nxt] = f4(nrm, __int_as_float(meta));
+                            pb.P3[nxt] = f4(ncol, new_tot);
+                            pb.tri[nxt] = best_i;
+                            pb.carry[pid] = FROM_CAMERA ? b.c_p : b.l_p;   // next_ray, :500 / :504
+                            alive = true;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (last) return;                                   // uniform: no queue after the final bounce
+    const unsigned idx = block_compact_index(alive, count_out);
+    if (alive) queue_out[idx] = pid;
+}
+
+// ---------------------------------------------------------------- connection stage
+// cosine_geometry_term, trace.metal:539-544: uses the STORED outgoing directions.
+__device__ __forceinline__ float geom_term(float cos_a, float cos_b, V3 oa, V3 ob) {
+    const float dist = length3(ob - oa);
+    return cos_a * cos_b / (dist * dist);
+}
+
+__device__ __forceinline__ int conn_slot(int t, int s) { return (t - 1) * 6 + (s - 1); }
+
+// Cull test for one (t,s) pair, trace.metal:667-688 + :577-584; on success returns the ray.
+struct ConnVtx { V3 o, n; int meta; };
+__device__ __forceinline__ bool conn_ray(int t, const ConnVtx& lv, const ConnVtx& cv, const MaterialDev* mats,
+                                         V3 focal, V3 cam_dir, V3& dir) {
+    if (__float_as_int(mats[lv.meta & 0xFF].color_type.w) > 0) return false;
+    if (t == 1) {
+        dir = normalize(focal - lv.o);
+        return !(dot(dir, cam_dir) > 0.0f);
+    }
+    if (__float_as_int(mats[cv.meta & 0xFF].color_type.w) > 0) return false;
+    dir = normalize(cv.o - lv.o);
+    if (dot(lv.n, dir) < DELTA_F) return false;
+    if (dot(cv.n, -dir) < DELTA_F) return false;
+    return true;
+}
+
+// Enumerate strategy pairs per pixel, emit connection rays into a compacted queue.
+// Rays are ordered wave-by-wave, slot-major inside a wave, so consecutive queue entries come from
+// the same (t,s) strategy of neighbouring pixels.
+__global__ __launch_bounds__(BLOCK) void k_connect_setup(
+        int B, PathBufs lp, PathBufs cp, const MaterialDev* __restrict__ mats, CameraRec cam,
+        float4* __restrict__ cray0, float4* __restrict__ cray1, unsigned* __restrict__ ccount,
+        unsigned long long* __restrict__ cmask) {
+    __shared__ unsigned s_wave_total[WAVES_PER_BLOCK];
+    __shared__ unsigned s_base;
+    const int pid = blockIdx.x * BLOCK + threadIdx.x;
+    const bool valid = pid < B;
+    const int Lc = valid ? cp.len[pid] : 0, Ll = valid ? lp.len[pid] : 0;
+    const V3 focal = cam3(cam.focal_point), cam_dir = cam3(cam.direction);
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+
+    ConnVtx lv[MAX_VERTS];
+#pragma unroll
+    for (int s = 0; s < MAX_VERTS; s++) {
+        if (s < Ll) {
+            const float4 a = lp.P0[(size_t)s * B + pid], c = lp.P2[(size_t)s * B + pid];
+            lv[s] = ConnVtx{v3(a), v3(c), __float_as_int(c.w)};
+        } else lv[s] = ConnVtx{v3(0, 0, 0), v3(0, 0, 0), 0};
+    }
+    // pass 1: predicates
+    unsigned long long mine = 0;
+    unsigned wave_total = 0;
+#pragma unroll
+    for (int t = 1; t <= MAX_VERTS; t++) {
+        ConnVtx cv{v3(0, 0, 0), v3(0, 0, 0), 0};
+        if (t <= Lc) {
+            const float4 a = cp.P0[(size_t)(t - 1) * B + pid], c = cp.P2[(size_t)(t - 1) * B + pid];
+            cv = ConnVtx{v3(a), v3(c), __float_as_int(c.w)};
+        }
+#pragma unroll
+        for (int s = 1; s <= MAX_VERTS; s++) {
+            V3 dir;
+            const bool pred = (t <= Lc) && (s <= Ll) && conn_ray(t, lv[s - 1], cv, mats, focal, cam_dir, dir);
+            if (pred) mine |= 1ull << conn_slot(t, s);
+            wave_total += __popcll(__ballot(pred));
+        }
+    }
+    if (lane == 0) s_wave_total[wave] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int w = 0; w < WAVES_PER_BLOCK; w++) tot += s_wave_total[w];
+        s_base = tot ? atomicAdd(ccount, tot) : 0u;
+    }
+    __syncthreads();
+    unsigned running = s_base;
+    for (int w = 0; w < wave; w++) running += s_wave_total[w];
+    if (valid) cmask[pid] = mine;
+    // pass 2: write rays
+#pragma unroll
+    for (int t = 1; t <= MAX_VERTS; t++) {
+        ConnVtx cv{v3(0, 0, 0), v3(0, 0, 0), 0};
+        if (t <= Lc) {
+            const float4 a = cp.P0[(size_t)(t - 1) * B + pid], c = cp.P2[(size_t)(t - 1) * B + pid];
+            cv = ConnVtx{v3(a), v3(c), __float_as_int(c.w)};
+        }
+#pragma unroll
+        for (int s = 1; s <= MAX_VERTS; s++) {
+            const int slot = conn_slot(t, s);
+            const bool pred = (mine >> slot) & 1ull;
+            const unsigned long long m = __ballot(pred);
+            if (pred) {
+                V3 dir;
+                conn_ray(t, lv[s - 1], cv, mats, focal, cam_dir, dir);
+                const unsigned idx = running + __popcll(m & ((1ull << lane) - 1ull));
+                cray0[idx] = f4(lv[s - 1].o, __int_as_float((slot << TAG_PID_BITS) | pid));
+                cray1[idx] = f4(dir, 0.0f);
+            }
+            running += __popcll(m);
+        }
+    }
+}
+
+// Closest hit for each connection ray; result scattered to chit[slot*B + pid] = {tri, t}.
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_traverse_conn(
+        BvhView bvh, int B, const unsigned* __restrict__ count, const float4* __restrict__ cray0,
+        const float4* __restrict__ cray1, float2* __restrict__ chit, Stats* stats) {
+    __shared__ BvhLds lds;
+    stage_bvh(lds, bvh);
+    const unsigned n = *count;
+    unsigned nb = 0, nt = 0;
+    for (unsigned j = blockIdx.x * BLOCK + threadIdx.x; j < n; j += gridDim.x * BLOCK) {
+        const float4 a = cray0[j], b4 = cray1[j];
+        const V3 o = v3(a), d = v3(b4);
+        const int tag = __float_as_int(a.w);
+        const Hit h = closest_hit<COUNT>(lds, bvh, o, d, rcp3(d), nb, nt);
+        const int pid = tag & ((1 << TAG_PID_BITS) - 1), slot = (unsigned)tag >> TAG_PID_BITS;
+        chit[(size_t)slot * B + pid] = make_float2(__int_as_float(h.tri), h.t);
+    }
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) { nb += __shfl_down(nb, off); nt += __shfl_down(nt, off); }
+        if (lane_id() == 0) {
+            atomicAdd(&stats->box_tests, (unsigned long long)nb);
+            atomicAdd(&stats->tri_tests, (unsigned long long)nt);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&stats->rays, (unsigned long long)n);
+        atomicAdd(&stats->conn_rays, (unsigned long long)n);
+        if (COUNT) atomicAdd(&stats->counted_rays, (unsigned long long)n);
+    }
+}
+
+// Aggregator SoA rows: 0..8 weights[i][j] (row i*3+j), 9..11 total_contribution, 12 contrib_weight_sum.
+constexpr int AGG_ROWS = 13;
+
+// Per-pixel strategy loop of connect_paths (trace.metal:649-868) with the BVH queries replaced by
+// the results of traverse_conn.  Accumulation order is the reference's, so the aggregator is
+// reproducible; only the t=1 splats (float atomics) are order-dependent.
+__global__ __launch_bounds__(BLOCK) void k_connect_resolve(
+        int B, PathBufs lp, PathBufs cp, const MaterialDev* __restrict__ mats,
+        const float4* __restrict__ tri_shade, CameraRec cam, const unsigned long long* __restrict__ cmask,
+        const float2* __restrict__ chit, float* __restrict__ agg, float4* __restrict__ light_image,
+        float4* __restrict__ uni_out, Stats* stats) {
+    const int pid = blockIdx.x * BLOCK + threadIdx.x;
+    if (pid >= B) return;
+    const int Lc = cp.len[pid], Ll = lp.len[pid];
+    const unsigned long long mask = cmask[pid];
+    const V3 focal = cam3(cam.focal_point), cam_dir = cam3(cam.direction);
+
+    // per-vertex scalars of both subpaths
+    float l_c[MAX_VERTS], l_l[MAX_VERTS], l_cos[MAX_VERTS], c_c[MAX_VERTS], c_l[MAX_VERTS], c_cos[MAX_VERTS];
+    float GL[MAX_VERTS], GC[MAX_VERTS];     // GL[v] = G(light[v], light[v+1]), GC likewise
+    unsigned l_spec = 0, c_spec = 0;        // bit v: material type > 0
+    {
+        V3 prev_o = v3(0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < MAX_VERTS; v++) {
+            l_c[v] = l_l[v] = l_cos[v] = GL[v] = 0.0f;
+            if (v < Ll) {
+                const size_t k = (size_t)v * B + pid;
+                const float4 a = lp.P0[k], b = lp.P1[k], c = lp.P2[k];
+                l_c[v] = a.w; l_l[v] = b.w;
+                l_cos[v] = __builtin_fabsf(dot(v3(b), v3(c)));
+                if (__float_as_int(mats[__float_as_int(c.w) & 0xFF].color_type.w) > 0) l_spec |= 1u << v;
+                if (v > 0) GL[v - 1] = geom_term(l_cos[v - 1], l_cos[v], prev_o, v3(a));
+                prev_o = v3(a);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < MAX_VERTS; v++) {
+            c_c[v] = c_l[v] = c_cos[v] = GC[v] = 0.0f;
+            if (v < Lc) {
+                const size_t k = (size_t)v * B + pid;
+                const float4 a = cp.P0[k], b = cp.P1[k], c = cp.P2[k];
+                c_c[v] = a.w; c_l[v] = b.w;
+                c_cos[v] = __builtin_fabsf(dot(v3(b), v3(c)));
+                if (__float_as_int(mats[__float_as_int(c.w) & 0xFF].color_type.w) > 0) c_spec |= 1u << v;
+                if (v > 0) GC[v - 1] = geom_term(c_cos[v - 1], c_cos[v], prev_o, v3(a));
+                prev_o = v3(a);
+            }
+        }
+    }
+
+    V3 total = v3(0, 0, 0);
+    float contrib_weight_sum = 0.0f;
+
+    for (int t = 1; t < Lc + 1; t++) {
+        // camera vertex t-1 (the stored one; for t == 1 the projected vertex replaces it per s)
+        const size_t ck = (size_t)(t - 1) * B + pid;
+        const float4 cP0 = cp.P0[ck], cP2 = cp.P2[ck], cP3 = cp.P3[ck];
+        const int c_meta = __float_as_int(cP2.w);
+        const int c_tri = cp.tri[ck];
+        V3 prior_camera_color = v3(0, 0, 0);
+        if (t >= 2) prior_camera_color = v3(cp.P3[ck - B]);
+
+        for (int s = 0; s < Ll + 1; s++) {
+            if (t + s < 2) continue;
+            // junction data
+            V3 l_o = v3(0, 0, 0), l_n = v3(0, 0, 0), dir_l_to_c = v3(0, 0, 0);
+            float l_tot = 1.0f, l_cos_s = 0.0f;
+            int l_meta = 0;
+            V3 c_o = v3(cP0), c_n = v3(cP2);
+            float c_tot = cP3.w, c_cos_t = c_cos[t - 1];
+            int cm_meta = c_meta;
+            int light_pixel_idx = -1;
+
+            if (s == 0) {
+                if (!(c_meta & META_HIT_LIGHT)) continue;                       // :665
+            } else {
+                const size_t lk = (size_t)(s - 1) * B + pid;
+                if (!((mask >> conn_slot(t, s)) & 1ull)) continue;              // culled in setup
+                const float4 lP0 = lp.P0[lk], lP2 = lp.P2[lk];
+                l_o = v3(lP0); l_n = v3(lP2); l_meta = __float_as_int(lP2.w);
+                l_tot = lp.P3[lk].w; l_cos_s = l_cos[s - 1];
+                const float2 h = chit[(size_t)conn_slot(t, s) * B + pid];
+                const int best_i = __float_as_int(h.x);
+                const int l_tri = lp.tri[lk];
+                if (t == 1) {
+                    // world_ray_to_camera_ray, trace.metal:593-616
+                    if (best_i == -1) continue;
+                    if (__float_as_int(tri_shade[4 * best_i + 2].w) == 0) continue;   // !is_camera
+                    const V3 tdir = normalize(focal - l_o);
+                    const V3 camera_point = l_o + h.y * tdir;
+                    const float x = dot(camera_point - cam3(cam.center), cam3(cam.dx));
+                    const float y = dot(camera_point - cam3(cam.center), cam3(cam.dy));
+                    const int pixel_x = (int)__builtin_roundf((x / cam.phys_width + 0.5f) * cam.pixel_width);
+                    const int pixel_y = (int)__builtin_roundf((y / cam.phys_height + 0.5f) * cam.pixel_height);
+                    light_pixel_idx = pixel_y * cam.pixel_width + pixel_x;
+                    if (light_pixel_idx == -1) continue;                        // :671
+                    c_o = camera_point;
+                    const V3 cdir = normalize(focal - camera_point);
+                    c_n = cam_dir;
+                    c_cos_t = __builtin_fabsf(dot(cdir, cam_dir));
+                    c_tot = 1.0f;
+                    cm_meta = 7 | META_HIT_CAMERA;
+                    dir_l_to_c = normalize(c_o - l_o);
+                } else {
+                    // visibility_test, trace.metal:193-196
+                    if (best_i == -1) continue;
+                    if (best_i == l_tri) continue;
+                    if (best_i != c_tri) continue;
+                    dir_l_to_c = normalize(c_o - l_o);
+                }
+            }
+
+            const int k = s + t - 1;                       // last unified vertex index
+            float Gj = 0.0f;
+            if (s > 0) Gj = geom_term(l_cos_s, c_cos_t, l_o, c_o);
+            // unified accessors (get_ray, trace.metal:546-549)
+            auto xl = [&](int i) { return i < s ? l_l[i] : c_l[t + s - i - 1]; };
+            auto xc = [&](int i) { return i < s ? l_c[i] : c_c[t + s - i - 1]; };
+            auto Gadj = [&](int i) {                       // G(x_i, x_{i+1})
+                return (i + 1 < s) ? GL[i] : ((i + 1 == s) ? Gj : GC[t + s - i - 2]);
+            };
+            float p_ratios[14], p_values[15];
+#pragma unroll
+            for (int i = 0; i < 14; i++) p_ratios[i] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 15; i++) p_values[i] = 0.0f;
+            for (int i = 0; i < s + t; i++) {              // :709-735
+                float num, denom;
+                if (i == 0) { num = xl(0); denom = xc(0) * Gadj(0); }
+                else if (i == k) { num = xl(k) * Gadj(k - 1); denom = xc(k); }
+                else { num = xl(i) * Gadj(i - 1); denom = xc(i) * Gadj(i); }
+                p_ratios[i] = num / denom;
+            }
+            const float p_s = c_tot * ((s == 0) ? 1.0f : l_tot);                 // :737-743
+            float p_i = p_s;
+            for (int i = s; i < s + t + 1; i++) { p_values[i + 1] = p_ratios[i] * p_i; p_i = p_values[i + 1]; }
+            p_i = p_s;
+            for (int i = s - 1; i >= 0; i--) { p_values[i] = p_i / p_ratios[i]; p_i = p_values[i]; }
+            p_values[s] = p_s;
+            for (int i = 0; i < s + t; i++) {              // :759-764
+                bool spec;
+                if (i < s) spec = (l_spec >> i) & 1u;
+                else {
+                    const int m = t + s - i - 1;
+                    spec = (t == 1 && s > 0) ? false /* projected vertex: material 7 */ : ((c_spec >> m) & 1u);
+                }
+                if (spec) { p_values[i] = 0.0f; p_values[i + 1] = 0.0f; }
+            }
+            p_values[s + t] = 0.0f;
+            float sum = 0.0f;
+            for (int i = 0; i < s + t + 1; i++) sum += p_values[i];
+            if (!(p_values[s] > 0.0f && sum > 0.0f)) continue;
+            const float w = p_values[s] / sum;
+
+            if (s == 0) {                                   // :783-786
+                const V3 emission = v3(mats[cm_meta & 0xFF].emission_alpha);
+                const V3 color = prior_camera_color * emission;
+                total = total + ((w * 1.0f) * color) / p_s;
+                contrib_weight_sum += w;
+            } else if (t == 1) {                            // :787-793, :817-823, and K8 :952-961
+                const int prior = (s - 2) > 0 ? (s - 2) : 0;
+                const V3 prior_color = v3(lp.P3[(size_t)prior * B + pid]);
+                float new_light_f = 1.0f;
+                if (s > 1) new_light_f = __builtin_fabsf(dot(dir_l_to_c, l_n)) / PI_F;
+                const V3 mcol = v3(mats[l_meta & 0xFF].color_type);
+                const float shade = new_light_f * Gj / p_s;
+                if (light_pixel_idx >= 0 && light_pixel_idx < B) {
+                    const V3 c = ((w * shade) * prior_color) * mcol;
+                    float* dst = reinterpret_cast<float*>(&light_image[light_pixel_idx]);
+                    atomicAdd(dst + 0, c.x);
+                    atomicAdd(dst + 1, c.y);
+                    atomicAdd(dst + 2, c.z);
+                    atomicAdd(dst + 3, w);
+                }
+            } else {                                        // :794-816
+                const MaterialDev cmat = mats[cm_meta & 0xFF];
+                const float new_camera_f = __builtin_fabsf(dot(-dir_l_to_c, c_n)) / PI_F;
+                const V3 camera_color = (prior_camera_color * new_camera_f) * v3(cmat.color_type);
+                V3 light_color;
+                if (s == 1) light_color = v3(mats[l_meta & 0xFF].emission_alpha);
+                else {
+                    const V3 prior_light_color = v3(lp.P3[(size_t)(s - 2) * B + pid]);
+                    const float new_light_f = __builtin_fabsf(dot(dir_l_to_c, l_n)) / PI_F;
+                    light_color = (prior_light_color * new_light_f) * v3(mats[l_meta & 0xFF].color_type);
+                }
+                const V3 color = camera_color * light_color;
+                total = total + ((w * Gj) * color) / p_s;
+                contrib_weight_sum += w;
+            }
+        }
+    }
+
+    // reconstruction-filter weights, trace.metal:827-862.  A zero-length camera path is the
+    // reference's zero-filled Path: pixel 0, film point (0,0,0).
+    const int pixel_idx = (Lc > 0) ? pid : 0;
+    V3 film = v3(0, 0, 0);
+    if (Lc > 0) film = v3(cp.P0[pid]);
+    const float ppw = cam.phys_width / cam.pixel_width, pph = cam.phys_height / cam.pixel_height;
+    const float sigma = 0.5f * __builtin_sqrtf(ppw * ppw + pph * pph);
+    float wts[9];
+    float weight_sum = 0.0f;
+#pragma unroll
+    for (int i = -1; i < 2; i++) {
+#pragma unroll
+        for (int j = -1; j < 2; j++) {
+            wts[(i + 1) * 3 + (j + 1)] = 0.0f;
+            const int nx = (pixel_idx % cam.pixel_width) + i, ny = (pixel_idx / cam.pixel_width) + j;
+            if (nx < 0 || nx >= cam.pixel_width || ny < 0 || ny >= cam.pixel_height) continue;
+            // pixel_center, trace.metal:551-562 (no +0.5)
+            const float xn = (nx - 0.5f * cam.pixel_width) / (float)cam.pixel_width;
+            const float yn = (ny - 0.5f * cam.pixel_height) / (float)cam.pixel_height;
+            const V3 pc = (cam3(cam.center) + (xn * cam.phys_width) * cam3(cam.dx)) + (yn * cam.phys_height) * cam3(cam.dy);
+            const float dist = length3(pc - film);
+            const float wgt = det_expf(-dist * dist / (2.0f * sigma * sigma));
+            wts[(i + 1) * 3 + (j + 1)] = wgt;
+            weight_sum += wgt;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 9; r++) agg[(size_t)r * B + pid] = (weight_sum != 0.0f) ? wts[r] / weight_sum : wts[r];
+    agg[(size_t)9 * B + pid] = total.x;
+    agg[(size_t)10 * B + pid] = total.y;
+    agg[(size_t)11 * B + pid] = total.z;
+    agg[(size_t)12 * B + pid] = contrib_weight_sum;
+
+    // unidirectional estimate of generate_paths (camera pass), trace.metal:523-528
+    float4 uni = make_float4(0, 0, 0, 0);
+    for (int v = 1; v < Lc; v++) {
+        const size_t kk = (size_t)v * B + pid;
+        if (__float_as_int(cp.P2[kk].w) & META_HIT_LIGHT) {
+            const V3 c = v3(cp.P3[kk - B]) / cp.P3[kk].w;
+            uni = make_float4(c.x, c.y, c.z, 1.0f);
+            break;
+        }
+    }
+    uni_out[pid] = uni;
+}
+
+// ---------------------------------------------------------------- K6: adaptive_finalize_samples
+// trace.metal:981-1018 with identity sample bins (renderer.py:92-94).
+__global__ __launch_bounds__(BLOCK) void k_finalize(int B, int W, int H, const float* __restrict__ agg,
+                                                    float4* __restrict__ finalized, float* __restrict__ sample_w) {
+    const int id = blockIdx.x * BLOCK + threadIdx.x;
+    if (id >= B) return;
+    V3 total = v3(0, 0, 0);
+    float wsum = 0.0f;
+    for (int i = -1; i < 2; i++) {
+        for (int j = -1; j < 2; j++) {
+            const int sx = (id % W) + i, sy = (id / W) + j;
+            if (sx < 0 || sx >= W || sy < 0 || sy >= H) continue;
+            const size_t k = (size_t)sy * W + sx;
+            const float weight = agg[(size_t)((1 - i) * 3 + (1 - j)) * B + k];
+            total = total + weight * v3(agg[(size_t)9 * B + k], agg[(size_t)10 * B + k], agg[(size_t)11 * B + k]);
+            wsum += weight * agg[(size_t)12 * B + k];
+        }
+    }
+    finalized[id] = make_float4(total.x, total.y, total.z, 1.0f);
+    sample_w[id] = wsum;
+}
+
+__device__ __forceinline__ float scrub(float x) {   // np.nan_to_num(x, posinf=0, neginf=0)
+    return (x != x || __builtin_isinf(x)) ? 0.0f : x;
+}
+
+// ---------------------------------------------------------------- process_images, renderer.py:253-278
+// Accumulators stay on the device: acc rows = summed_image rgb (0..2), summed_sample_weights (3),
+// unidirectional rgb (4..6), summed_sample_counts as float (7).  The light image is zeroed for the
+// next sample.
+__global__ __launch_bounds__(BLOCK) void k_accumulate(int B, const float4* __restrict__ finalized,
+                                                      const float* __restrict__ sample_w, float4* __restrict__ light_image,
+                                                      const float4* __restrict__ uni, float* __restrict__ acc) {
+    const int id = blockIdx.x * BLOCK + threadIdx.x;
+    if (id >= B) return;
+    const float4 f = finalized[id], l = light_image[id], u = uni[id];
+    acc[(size_t)0 * B + id] += scrub(l.x + f.x);
+    acc[(size_t)1 * B + id] += scrub(l.y + f.y);
+    acc[(size_t)2 * B + id] += scrub(l.z + f.z);
+    acc[(size_t)3 * B + id] += sample_w[id] + l.w;      // K8's `sum_weights[id] += weight_sum`, :963
+    acc[(size_t)4 * B + id] += scrub(u.x);
+    acc[(size_t)5 * B + id] += scrub(u.y);
+    acc[(size_t)6 * B + id] += scrub(u.z);
+    acc[(size_t)7 * B + id] += 1.0f;
+    light_image[id] = make_float4(0, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------- debug exports (reference AoS)
+struct RayRec {   // struct Ray, trace.metal:7-23
+    float origin[4], direction[4], inv_direction[4], color[4], normal[4];
+    int material, triangle;
+    float c_importance, l_importance, tot_importance;
+    int hit_light, from_camera, hit_camera, pixel_idx;
+    int pad[3];
+};
+static_assert(sizeof(RayRec) == 128, "Ray record");
+
+__device__ __forceinline__ void fill_ray(RayRec& r, const PathBufs& pb, size_t k, int from_camera, int pixel_idx) {
+    const float4 a = pb.P0[k], b = pb.P1[k], c = pb.P2[k], d = pb.P3[k];
+    const int meta = __float_as_int(c.w), tri = pb.tri[k];
+    r.origin[0] = a.x; r.origin[1] = a.y; r.origin[2] = a.z; r.origin[3] = 0;
+    r.direction[0] = b.x; r.direction[1] = b.y; r.direction[2] = b.z; r.direction[3] = 0;
+    r.inv_direction[0] = 1.0f / b.x; r.inv_direction[1] = 1.0f / b.y; r.inv_direction[2] = 1.0f / b.z; r.inv_direction[3] = 0;
+    r.color[0] = d.x; r.color[1] = d.y; r.color[2] = d.z; r.color[3] = 0;
+    r.normal[0] = c.x; r.normal[1] = c.y; r.normal[2] = c.z; r.normal[3] = 0;
+    r.material = meta & 0xFF; r.triangle = tri;
+    r.c_importance = a.w; r.l_importance = b.w; r.tot_importance = d.w;
+    r.hit_light = (meta & META_HIT_LIGHT) ? tri : -1;
+    r.from_camera = from_camera;
+    r.hit_camera = (meta & META_HIT_CAMERA) ? tri : -1;
+    r.pixel_idx = pixel_idx;
+    r.pad[0] = r.pad[1] = r.pad[2] = 0;
+}
+
+__global__ void k_export_rays(int B, PathBufs pb, int from_camera, RayRec* out) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B) return;
+    RayRec r;
+    fill_ray(r, pb, id, from_camera, from_camera ? id : 0);
+    out[id] = r;
+}
+
+// Path record = 8 RayRec + length + from_camera + pad[2] (1040 B).  Slots >= length are zero.
+__global__ void k_export_paths(int B, PathBufs pb, int from_camera, unsigned char* out) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B) return;
+    unsigned char* rec = out + (size_t)id * 1040;
+    const int len = pb.len[id];
+    for (int v = 0; v < 8; v++) {
+        RayRec r;
+        if (v < len) fill_ray(r, pb, (size_t)v * B + id, v == 0 ? from_camera : 0, (v == 0 && from_camera) ? id : 0);
+        else memset(&r, 0, sizeof r);
+        *reinterpret_cast<RayRec*>(rec + 128 * v) = r;
+    }
+    int* tail = reinterpret_cast<int*>(rec + 1024);
+    tail[0] = len; tail[1] = from_camera; tail[2] = 0; tail[3] = 0;
+}
+
+// WeightAggregator records at the reference's 128-byte host stride (renderer.py:71).
+__global__ void k_export_aggregators(int B, const float* __restrict__ agg, float* out) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B) return;
+    float* rec = out + (size_t)id * 32;
+    for (int i = 0; i < 32; i++) rec[i] = 0.0f;
+    for (int r = 0; r < 9; r++) rec[r] = agg[(size_t)r * B + id];
+    rec[12] = agg[(size_t)9 * B + id]; rec[13] = agg[(size_t)10 * B + id]; rec[14] = agg[(size_t)11 * B + id];
+    rec[16] = agg[(size_t)12 * B + id];
+}
+
+}  // namespace cl2

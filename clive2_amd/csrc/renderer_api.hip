@@ -1,0 +1,661 @@
+// renderer_api.hip -- host side of libclive2_amd.so: device-memory ownership, scene repacking,
+// launch sequencing on one HIP stream, HIP-event stage timers, and the extern "C" entry points
+// declared in include/clive2_amd.h.
+//
+// Stage order and buffer roles follow Renderer.run_sample (src/renderer.py:281-291); what differs
+// is where the state lives (SoA on the device, accumulators included) and that nothing returns to
+// the host between samples.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/clive2_amd.h"
+#include "kernels.hpp"
+
+using namespace cl2;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// Reference AoS records as the host hands them over (src/struct_types.py).
+struct BoxRec { float min[4], max[4]; int32_t left, right, pad[2]; };
+struct TriRec { float v0[4], v1[4], v2[4], n0[4], n1[4], n2[4], normal[4]; int32_t material, is_light, is_camera, pad; };
+struct MatRec { float color[4], emission[4]; int32_t type; float alpha, ior; int32_t pad; };
+static_assert(sizeof(BoxRec) == 48 && sizeof(TriRec) == 128 && sizeof(MatRec) == 48 && sizeof(CameraRec) == 112, "ABI");
+
+enum Stage { ST_GENERATE, ST_TRAVERSE_PATHS, ST_BOUNCE, ST_CONNECT_SETUP, ST_TRAVERSE_CONN, ST_CONNECT_RESOLVE,
+             ST_FINALIZE, ST_ACCUMULATE, ST_COUNT };
+
+template <typename T> struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+};
+
+}  // namespace
+
+struct cl2_renderer {
+    int device = 0, W = 0, H = 0, B = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool scene_ok = false, profiling = false, counting = false;
+
+    // scene
+    BvhView bvh{};
+    float4 *d_nodes = nullptr, *d_tris = nullptr, *d_tri_shade = nullptr, *d_light_tris = nullptr;
+    int *d_skip = nullptr, *d_light_tri_index = nullptr;
+    float* d_light_areas = nullptr;
+    MaterialDev* d_mats = nullptr;
+    int n_mats = 0, light_count = 0;
+    CameraRec cam{};
+
+    // state
+    uint2* d_seeds = nullptr;
+    PathBufs pb[2]{};
+    float4* d_hit = nullptr;
+    int* d_queue = nullptr;            // [6][B], shared by both subpath kinds (they run one after the other)
+    unsigned* d_qcount = nullptr;      // [8]: [0] = B (level-0 count), [1..6] level counts, [7] connection rays
+    float4 *d_cray0 = nullptr, *d_cray1 = nullptr;
+    size_t cray_cap = 0;
+    float2* d_chit = nullptr;
+    unsigned long long* d_cmask = nullptr;
+    float* d_agg = nullptr;
+    float4 *d_light_image = nullptr, *d_finalized = nullptr, *d_uni = nullptr;
+    float* d_sample_w = nullptr;
+    float* d_acc = nullptr;            // [8][B]
+    Stats* d_stats = nullptr;
+
+    // host-side tallies
+    uint64_t samples = 0, counted_rays = 0;
+    double ms[ST_COUNT] = {0};
+    uint64_t launches_tp = 0, launches_tc = 0, rays_tp = 0, rays_tc = 0;
+    struct Span { hipEvent_t a, b; int stage; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
+
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+#define HIP_TRY(r, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (r)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                         \
+            return CL2_E_HIP;                                                                     \
+        }                                                                                         \
+    } while (0)
+
+template <typename T> int dev_alloc(cl2_renderer* r, T** p, size_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) { r->err = std::string("hipMalloc: ") + hipGetErrorString(e); return CL2_E_NOMEM; }
+    r->allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return CL2_OK;
+}
+
+template <typename T> void dev_free(cl2_renderer* r, T*& p) {
+    if (!p) return;
+    auto it = std::find(r->allocs.begin(), r->allocs.end(), static_cast<void*>(p));
+    if (it != r->allocs.end()) r->allocs.erase(it);
+    (void)hipFree(p);
+    p = nullptr;
+}
+
+int fail(cl2_renderer* r, int code, const std::string& msg) { r->err = msg; return code; }
+
+inline int grid_for(size_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
+
+hipEvent_t take_event(cl2_renderer* r) {
+    if (!r->event_pool.empty()) { hipEvent_t e = r->event_pool.back(); r->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct Timed {   // records a HIP-event span around a launch when profiling is on
+    cl2_renderer* r; int stage; hipEvent_t a = nullptr;
+    Timed(cl2_renderer* r_, int st) : r(r_), stage(st) {
+        if (r->profiling) { a = take_event(r); (void)hipEventRecord(a, r->stream); }
+    }
+    ~Timed() {
+        if (a) { hipEvent_t b = take_event(r); (void)hipEventRecord(b, r->stream); r->spans.push_back({a, b, stage}); }
+    }
+};
+
+int drain(cl2_renderer* r) {
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    for (auto& s : r->spans) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) r->ms[s.stage] += ms;
+        r->event_pool.push_back(s.a);
+        r->event_pool.push_back(s.b);
+    }
+    r->spans.clear();
+    return CL2_OK;
+}
+
+// ---- launches (asynchronous on r->stream) ----
+int launch_generate(cl2_renderer* r, int which) {
+    Timed t(r, ST_GENERATE);
+    if (which == CL2_LIGHT)
+        hipLaunchKernelGGL(k_gen_light_rays, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->d_light_tris,
+                           r->d_light_areas, r->d_light_tri_index, r->d_mats, r->light_count, r->d_seeds, r->pb[CL2_LIGHT]);
+    else
+        hipLaunchKernelGGL(k_gen_camera_rays, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->cam, r->d_seeds,
+                           r->pb[CL2_CAMERA]);
+    HIP_TRY(r, hipGetLastError());
+    return CL2_OK;
+}
+
+int launch_trace(cl2_renderer* r, int which) {
+    const int B = r->B;
+    PathBufs pb = r->pb[which];
+    HIP_TRY(r, hipMemsetAsync(r->d_qcount + 1, 0, 6 * sizeof(unsigned), r->stream));
+    for (int level = 0; level < MAX_VERTS; level++) {
+        const int* q_in = level == 0 ? nullptr : r->d_queue + (size_t)(level - 1) * B;
+        const unsigned* c_in = r->d_qcount + level;            // [0] holds B
+        int* q_out = r->d_queue + (size_t)level * B;
+        unsigned* c_out = r->d_qcount + level + 1;
+        {
+            Timed t(r, ST_TRAVERSE_PATHS);
+            if (r->counting)
+                hipLaunchKernelGGL(k_traverse_paths<true>, dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, r->bvh, q_in, c_in,
+                                   pb.P0 + (size_t)level * B, pb.P1 + (size_t)level * B, r->d_hit, r->d_stats);
+            else
+                hipLaunchKernelGGL(k_traverse_paths<false>, dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, r->bvh, q_in, c_in,
+                                   pb.P0 + (size_t)level * B, pb.P1 + (size_t)level * B, r->d_hit, r->d_stats);
+            r->launches_tp++;
+        }
+        HIP_TRY(r, hipGetLastError());
+        {
+            Timed t(r, ST_BOUNCE);
+            const int last = level == MAX_VERTS - 1;
+            if (which == CL2_CAMERA)
+                hipLaunchKernelGGL(k_bounce<true>, dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, level, last, q_in, c_in, q_out,
+                                   c_out, B, pb, r->d_hit, r->d_seeds, r->d_tri_shade, r->d_mats);
+            else
+                hipLaunchKernelGGL(k_bounce<false>, dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, level, last, q_in, c_in, q_out,
+                                   c_out, B, pb, r->d_hit, r->d_seeds, r->d_tri_shade, r->d_mats);
+        }
+        HIP_TRY(r, hipGetLastError());
+    }
+    return CL2_OK;
+}
+
+int launch_join(cl2_renderer* r) {
+    const int B = r->B;
+    HIP_TRY(r, hipMemsetAsync(r->d_qcount + 7, 0, sizeof(unsigned), r->stream));
+    {
+        Timed t(r, ST_CONNECT_SETUP);
+        hipLaunchKernelGGL(k_connect_setup, dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, B, r->pb[CL2_LIGHT], r->pb[CL2_CAMERA],
+                           r->d_mats, r->cam, r->d_cray0, r->d_cray1, r->d_qcount + 7, r->d_cmask);
+    }
+    HIP_TRY(r, hipGetLastError());
+    {
+        Timed t(r, ST_TRAVERSE_CONN);
+        // grid-stride over the (device-side) ray count; enough workgroups to fill 256 CUs several times over
+        const int grid = std::min<size_t>(grid_for((size_t)B * 8), 256 * 32);
+        if (r->counting)
+            hipLaunchKernelGGL(k_traverse_conn<true>, dim3(grid), dim3(BLOCK), 0, r->stream, r->bvh, B, r->d_qcount + 7, r->d_cray0,
+                               r->d_cray1, r->d_chit, r->d_stats);
+        else
+            hipLaunchKernelGGL(k_traverse_conn<false>, dim3(grid), dim3(BLOCK), 0, r->stream, r->bvh, B, r->d_qcount + 7, r->d_cray0,
+                               r->d_cray1, r->d_chit, r->d_stats);
+        r->launches_tc++;
+    }
+    HIP_TRY(r, hipGetLastError());
+    {
+        Timed t(r, ST_CONNECT_RESOLVE);
+        hipLaunchKernelGGL(k_connect_resolve, dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, B, r->pb[CL2_LIGHT], r->pb[CL2_CAMERA],
+                           r->d_mats, r->d_tri_shade, r->cam, r->d_cmask, r->d_chit, r->d_agg, r->d_light_image, r->d_uni, r->d_stats);
+    }
+    HIP_TRY(r, hipGetLastError());
+    return CL2_OK;
+}
+
+int launch_finalize(cl2_renderer* r) {
+    Timed t(r, ST_FINALIZE);
+    hipLaunchKernelGGL(k_finalize, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->W, r->H, r->d_agg, r->d_finalized,
+                       r->d_sample_w);
+    HIP_TRY(r, hipGetLastError());
+    return CL2_OK;
+}
+
+int launch_accumulate(cl2_renderer* r) {
+    Timed t(r, ST_ACCUMULATE);
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->d_finalized, r->d_sample_w,
+                       r->d_light_image, r->d_uni, r->d_acc);
+    HIP_TRY(r, hipGetLastError());
+    return CL2_OK;
+}
+
+int need_scene(cl2_renderer* r) {
+    if (!r) return CL2_E_INVALID;
+    if (!r->scene_ok) return fail(r, CL2_E_STATE, "no scene uploaded (call cl2_upload_scene first)");
+    HIP_TRY(r, hipSetDevice(r->device));
+    return CL2_OK;
+}
+
+#define STAGE_PROLOGUE(r)                 \
+    do {                                  \
+        int rc_ = need_scene(r);          \
+        if (rc_ != CL2_OK) return rc_;    \
+    } while (0)
+#define TRY(expr)                         \
+    do {                                  \
+        int rc_ = (expr);                 \
+        if (rc_ != CL2_OK) return rc_;    \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int cl2_abi_version(void) { return 1; }
+
+const char* cl2_last_error(const cl2_renderer* r) { return r ? r->err.c_str() : g_create_error.c_str(); }
+
+int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_renderer** out) {
+    if (!out) { g_create_error = "out is NULL"; return CL2_E_INVALID; }
+    *out = nullptr;
+    if (pixel_width < 1 || pixel_height < 1 || (long long)pixel_width * pixel_height >= (1ll << TAG_PID_BITS)) {
+        g_create_error = "frame size out of range (need 1 <= W*H < 2^26)";
+        return CL2_E_INVALID;
+    }
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev < 1) {
+        g_create_error = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return CL2_E_HIP;
+    }
+    if (device_ordinal < 0 || device_ordinal >= n_dev) { g_create_error = "device ordinal out of range"; return CL2_E_INVALID; }
+    cl2_renderer* r = new cl2_renderer();
+    r->device = device_ordinal;
+    r->W = pixel_width; r->H = pixel_height; r->B = pixel_width * pixel_height;
+    const size_t B = (size_t)r->B;
+    auto bail = [&](int code) { g_create_error = r->err; cl2_destroy(r); return code; };
+    if (hipSetDevice(device_ordinal) != hipSuccess) { r->err = "hipSetDevice failed"; return bail(CL2_E_HIP); }
+    if (hipStreamCreate(&r->stream) != hipSuccess) { r->err = "hipStreamCreate failed"; return bail(CL2_E_HIP); }
+    int rc = CL2_OK;
+#define A(ptr, count) if (rc == CL2_OK) rc = dev_alloc(r, &(ptr), (count))
+    A(r->d_seeds, B);
+    for (int k = 0; k < 2; k++) {
+        A(r->pb[k].P0, MAX_VERTS * B); A(r->pb[k].P1, MAX_VERTS * B); A(r->pb[k].P2, MAX_VERTS * B); A(r->pb[k].P3, MAX_VERTS * B);
+        A(r->pb[k].tri, MAX_VERTS * B); A(r->pb[k].len, B); A(r->pb[k].carry, B);
+    }
+    A(r->d_hit, B);
+    A(r->d_queue, MAX_VERTS * B);
+    A(r->d_qcount, 8);
+    r->cray_cap = (size_t)CONN_SLOTS * B;
+    A(r->d_cray0, r->cray_cap); A(r->d_cray1, r->cray_cap);
+    A(r->d_chit, (size_t)CONN_SLOTS * B);
+    A(r->d_cmask, B);
+    A(r->d_agg, (size_t)AGG_ROWS * B);
+    A(r->d_light_image, B); A(r->d_finalized, B); A(r->d_uni, B);
+    A(r->d_sample_w, B);
+    A(r->d_acc, 8 * B);
+    A(r->d_stats, 1);
+#undef A
+    if (rc != CL2_OK) return bail(rc);
+    unsigned qc[8] = {(unsigned)r->B, 0, 0, 0, 0, 0, 0, 0};
+    bool ok = hipMemcpy(r->d_qcount, qc, sizeof qc, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemset(r->d_light_image, 0, B * sizeof(float4)) == hipSuccess;
+    ok = ok && hipMemset(r->d_finalized, 0, B * sizeof(float4)) == hipSuccess;
+    ok = ok && hipMemset(r->d_uni, 0, B * sizeof(float4)) == hipSuccess;
+    ok = ok && hipMemset(r->d_sample_w, 0, B * sizeof(float)) == hipSuccess;
+    ok = ok && hipMemset(r->d_acc, 0, 8 * B * sizeof(float)) == hipSuccess;
+    ok = ok && hipMemset(r->d_agg, 0, (size_t)AGG_ROWS * B * sizeof(float)) == hipSuccess;
+    ok = ok && hipMemset(r->d_stats, 0, sizeof(Stats)) == hipSuccess;
+    ok = ok && hipMemset(r->d_cmask, 0, B * sizeof(unsigned long long)) == hipSuccess;
+    for (int k = 0; k < 2 && ok; k++) ok = hipMemset(r->pb[k].len, 0, B * sizeof(int)) == hipSuccess;
+    // default seeds: 1 everywhere (xorshift's only forbidden state is 0); callers set real seeds
+    if (ok) {
+        std::vector<uint32_t> ones(2 * B, 1u);
+        ok = hipMemcpy(r->d_seeds, ones.data(), 2 * B * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) { r->err = "device buffer initialisation failed"; return bail(CL2_E_HIP); }
+    *out = r;
+    return CL2_OK;
+}
+
+void cl2_destroy(cl2_renderer* r) {
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    for (auto& s : r->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto e : r->event_pool) (void)hipEventDestroy(e);
+    for (void* p : r->allocs) (void)hipFree(p);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+
+int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const void* tris_v, int n_tris, const void* mats_v,
+                     int n_mats, const void* camera_v, const void* light_tris_v, const float* light_areas,
+                     const int32_t* light_tri_index, int light_count) {
+    if (!r) return CL2_E_INVALID;
+    if (!boxes_v || !tris_v || !mats_v || !camera_v || !light_tris_v || !light_areas || !light_tri_index)
+        return fail(r, CL2_E_INVALID, "NULL scene array");
+    if (n_boxes < 1 || n_tris < 1 || light_count < 1) return fail(r, CL2_E_INVALID, "scene needs >=1 box, triangle and light");
+    // material 7 is hard-wired into the camera vertices (trace.metal:611, :1053); at most 256 fit the packed meta word
+    if (n_mats < 8 || n_mats > 256) return fail(r, CL2_E_INVALID, "material table must have 8..256 entries");
+    const BoxRec* boxes = static_cast<const BoxRec*>(boxes_v);
+    const TriRec* tris = static_cast<const TriRec*>(tris_v);
+    const MatRec* mats = static_cast<const MatRec*>(mats_v);
+    const TriRec* ltris = static_cast<const TriRec*>(light_tris_v);
+    CameraRec cam;
+    std::memcpy(&cam, camera_v, sizeof cam);
+    if (cam.pixel_width != r->W || cam.pixel_height != r->H)
+        return fail(r, CL2_E_INVALID, "camera resolution differs from the renderer's");
+
+    // ---- validate the tree: every index in range and children after their parent (breadth-first
+    // numbering, src/bvh.py:345-351), which also guarantees the stackless walk terminates ----
+    std::vector<int> skip(n_boxes, -2);
+    std::vector<char> tri_seen(n_tris, 0);
+    skip[0] = -1;
+    for (int i = 0; i < n_boxes; i++) {
+        const BoxRec& b = boxes[i];
+        if (skip[i] == -2) return fail(r, CL2_E_INVALID, "box " + std::to_string(i) + " is not reachable from the root");
+        if (b.right == 0) {
+            if (b.left <= i || b.left + 1 >= n_boxes) return fail(r, CL2_E_INVALID, "inner box child index out of order/range");
+            if (skip[b.left] != -2 || skip[b.left + 1] != -2) return fail(r, CL2_E_INVALID, "box has two parents");
+            skip[b.left + 1] = b.left;     // right child is visited first; then its sibling
+            skip[b.left] = skip[i];        // after the left child, whatever followed the parent
+        } else {
+            if (b.left < 0 || b.right > n_tris || b.left >= b.right) return fail(r, CL2_E_INVALID, "leaf triangle range out of range");
+            for (int t = b.left; t < b.right; t++) tri_seen[t] = 1;
+        }
+    }
+    for (int t = 0; t < n_tris; t++) {
+        if (tris[t].material < 0 || tris[t].material >= n_mats) return fail(r, CL2_E_INVALID, "triangle material index out of range");
+    }
+    for (int l = 0; l < light_count; l++) {
+        if (light_tri_index[l] < 0 || light_tri_index[l] >= n_tris) return fail(r, CL2_E_INVALID, "light triangle index out of range");
+        if (ltris[l].material < 0 || ltris[l].material >= n_mats) return fail(r, CL2_E_INVALID, "light material index out of range");
+    }
+
+    // ---- repack ----
+    std::vector<float4> h_nodes(2 * (size_t)n_boxes), h_tris(3 * (size_t)n_tris), h_shade(4 * (size_t)n_tris),
+        h_ltris(5 * (size_t)light_count);
+    auto as_f = [](int32_t i) { float f; std::memcpy(&f, &i, 4); return f; };
+    for (int i = 0; i < n_boxes; i++) {
+        const BoxRec& b = boxes[i];
+        h_nodes[2 * i] = make_float4(b.min[0], b.min[1], b.min[2], as_f(b.left));
+        h_nodes[2 * i + 1] = make_float4(b.max[0], b.max[1], b.max[2], as_f(b.right));
+    }
+    for (int t = 0; t < n_tris; t++) {
+        const TriRec& T = tris[t];
+        // edge vectors: the same binary32 subtractions ray_triangle_intersect performs (trace.metal:118-119)
+        h_tris[3 * t] = make_float4(T.v0[0], T.v0[1], T.v0[2], 0.0f);
+        h_tris[3 * t + 1] = make_float4(T.v1[0] - T.v0[0], T.v1[1] - T.v0[1], T.v1[2] - T.v0[2], 0.0f);
+        h_tris[3 * t + 2] = make_float4(T.v2[0] - T.v0[0], T.v2[1] - T.v0[1], T.v2[2] - T.v0[2], 0.0f);
+        h_shade[4 * t] = make_float4(T.n0[0], T.n0[1], T.n0[2], as_f(T.material));
+        h_shade[4 * t + 1] = make_float4(T.n1[0], T.n1[1], T.n1[2], as_f(T.is_light ? 1 : 0));
+        h_shade[4 * t + 2] = make_float4(T.n2[0], T.n2[1], T.n2[2], as_f(T.is_camera ? 1 : 0));
+        h_shade[4 * t + 3] = make_float4(T.normal[0], T.normal[1], T.normal[2], 0.0f);
+    }
+    for (int l = 0; l < light_count; l++) {
+        const TriRec& T = ltris[l];
+        h_ltris[5 * l] = make_float4(T.v0[0], T.v0[1], T.v0[2], 0.0f);
+        h_ltris[5 * l + 1] = make_float4(T.v1[0], T.v1[1], T.v1[2], 0.0f);
+        h_ltris[5 * l + 2] = make_float4(T.v2[0], T.v2[1], T.v2[2], 0.0f);
+        h_ltris[5 * l + 3] = make_float4(T.normal[0], T.normal[1], T.normal[2], 0.0f);
+        h_ltris[5 * l + 4] = make_float4(as_f(T.material), 0.0f, 0.0f, 0.0f);
+    }
+    std::vector<MaterialDev> h_mats(n_mats);
+    for (int m = 0; m < n_mats; m++) {
+        h_mats[m].color_type = make_float4(mats[m].color[0], mats[m].color[1], mats[m].color[2], as_f(mats[m].type));
+        h_mats[m].emission_alpha = make_float4(mats[m].emission[0], mats[m].emission[1], mats[m].emission[2], mats[m].alpha);
+        h_mats[m].ior = mats[m].ior;
+        h_mats[m].pad[0] = h_mats[m].pad[1] = h_mats[m].pad[2] = 0.0f;
+    }
+
+    HIP_TRY(r, hipSetDevice(r->device));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    r->scene_ok = false;
+    dev_free(r, r->d_nodes); dev_free(r, r->d_skip); dev_free(r, r->d_tris); dev_free(r, r->d_tri_shade);
+    dev_free(r, r->d_mats); dev_free(r, r->d_light_tris); dev_free(r, r->d_light_areas); dev_free(r, r->d_light_tri_index);
+    TRY(dev_alloc(r, &r->d_nodes, h_nodes.size()));
+    TRY(dev_alloc(r, &r->d_skip, skip.size()));
+    TRY(dev_alloc(r, &r->d_tris, h_tris.size()));
+    TRY(dev_alloc(r, &r->d_tri_shade, h_shade.size()));
+    TRY(dev_alloc(r, &r->d_mats, h_mats.size()));
+    TRY(dev_alloc(r, &r->d_light_tris, h_ltris.size()));
+    TRY(dev_alloc(r, &r->d_light_areas, (size_t)light_count));
+    TRY(dev_alloc(r, &r->d_light_tri_index, (size_t)light_count));
+    HIP_TRY(r, hipMemcpy(r->d_nodes, h_nodes.data(), h_nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(r, hipMemcpy(r->d_skip, skip.data(), skip.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(r, hipMemcpy(r->d_tris, h_tris.data(), h_tris.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(r, hipMemcpy(r->d_tri_shade, h_shade.data(), h_shade.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(r, hipMemcpy(r->d_mats, h_mats.data(), h_mats.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
+    HIP_TRY(r, hipMemcpy(r->d_light_tris, h_ltris.data(), h_ltris.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(r, hipMemcpy(r->d_light_areas, light_areas, (size_t)light_count * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(r, hipMemcpy(r->d_light_tri_index, light_tri_index, (size_t)light_count * sizeof(int), hipMemcpyHostToDevice));
+
+    r->bvh.nodes = r->d_nodes; r->bvh.skip = r->d_skip; r->bvh.tris = r->d_tris;
+    r->bvh.n_nodes = n_boxes; r->bvh.n_tris = n_tris;
+    r->bvh.n_lds_nodes = std::min(n_boxes, LDS_NODE_CAP);
+    r->bvh.lds_tris = n_tris <= LDS_TRI_CAP ? 1 : 0;
+    r->n_mats = n_mats; r->light_count = light_count; r->cam = cam;
+    r->scene_ok = true;
+    return CL2_OK;
+}
+
+int cl2_set_seeds(cl2_renderer* r, const uint32_t* seeds, size_t n_words) {
+    if (!r || !seeds) return CL2_E_INVALID;
+    if (n_words != 2 * (size_t)r->B) return fail(r, CL2_E_INVALID, "seed buffer must hold 2 words per pixel");
+    HIP_TRY(r, hipSetDevice(r->device));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    HIP_TRY(r, hipMemcpy(r->d_seeds, seeds, n_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return CL2_OK;
+}
+
+int cl2_get_seeds(cl2_renderer* r, uint32_t* seeds, size_t n_words) {
+    if (!r || !seeds) return CL2_E_INVALID;
+    if (n_words != 2 * (size_t)r->B) return fail(r, CL2_E_INVALID, "seed buffer must hold 2 words per pixel");
+    HIP_TRY(r, hipSetDevice(r->device));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    HIP_TRY(r, hipMemcpy(seeds, r->d_seeds, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return CL2_OK;
+}
+
+int cl2_make_light_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_generate(r, CL2_LIGHT)); return drain(r); }
+int cl2_make_camera_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_generate(r, CL2_CAMERA)); return drain(r); }
+int cl2_trace_light_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_trace(r, CL2_LIGHT)); return drain(r); }
+int cl2_trace_camera_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_trace(r, CL2_CAMERA)); return drain(r); }
+int cl2_join_paths(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_join(r)); return drain(r); }
+int cl2_finalize_samples(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_finalize(r)); return drain(r); }
+/* The t=1 splats were added to the light image by join_paths (float atomics); nothing is left of the
+ * reference's sort + bincount + gather (src/renderer.py:212-250) but a synchronisation point. */
+int cl2_gather_light_image(cl2_renderer* r) { STAGE_PROLOGUE(r); return drain(r); }
+int cl2_process_images(cl2_renderer* r) {
+    STAGE_PROLOGUE(r);
+    TRY(launch_accumulate(r));
+    r->samples++;
+    return drain(r);
+}
+
+int cl2_run_samples(cl2_renderer* r, int n) {
+    STAGE_PROLOGUE(r);
+    if (n < 0) return fail(r, CL2_E_INVALID, "negative sample count");
+    for (int i = 0; i < n; i++) {
+        TRY(launch_generate(r, CL2_LIGHT));
+        TRY(launch_generate(r, CL2_CAMERA));
+        TRY(launch_trace(r, CL2_LIGHT));
+        TRY(launch_trace(r, CL2_CAMERA));
+        TRY(launch_join(r));
+        TRY(launch_finalize(r));
+        TRY(launch_accumulate(r));
+        r->samples++;
+        // bound the number of in-flight event pairs while profiling
+        if (r->profiling && r->spans.size() > 4096) TRY(drain(r));
+    }
+    return drain(r);
+}
+
+int cl2_read_accumulators(cl2_renderer* r, float* img, float* wts, int32_t* counts, float* uni, size_t n_pixels) {
+    if (!r) return CL2_E_INVALID;
+    if (n_pixels != (size_t)r->B) return fail(r, CL2_E_INVALID, "n_pixels must equal W*H");
+    HIP_TRY(r, hipSetDevice(r->device));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    const size_t B = r->B;
+    std::vector<float> h(8 * B);
+    HIP_TRY(r, hipMemcpy(h.data(), r->d_acc, 8 * B * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < B; p++) {
+        if (img) { img[3 * p] = h[p]; img[3 * p + 1] = h[B + p]; img[3 * p + 2] = h[2 * B + p]; }
+        if (wts) wts[p] = h[3 * B + p];
+        if (uni) { uni[3 * p] = h[4 * B + p]; uni[3 * p + 1] = h[5 * B + p]; uni[3 * p + 2] = h[6 * B + p]; }
+        if (counts) counts[p] = (int32_t)std::lrintf(h[7 * B + p]);
+    }
+    return CL2_OK;
+}
+
+int cl2_reset_accumulators(cl2_renderer* r) {
+    if (!r) return CL2_E_INVALID;
+    HIP_TRY(r, hipSetDevice(r->device));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    HIP_TRY(r, hipMemset(r->d_acc, 0, 8 * (size_t)r->B * sizeof(float)));
+    r->samples = 0;
+    return CL2_OK;
+}
+
+static int acc_copy(cl2_renderer* r, void* dst, const void* src, size_t n_floats, hipMemcpyKind kind) {
+    if (!r || !dst || !src) return CL2_E_INVALID;
+    if (n_floats != 8 * (size_t)r->B) return fail(r, CL2_E_INVALID, "packed accumulators hold 8*W*H floats");
+    HIP_TRY(r, hipSetDevice(r->device));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    HIP_TRY(r, hipMemcpy(dst, src, n_floats * sizeof(float), kind));
+    return CL2_OK;
+}
+int cl2_read_accumulators_packed(cl2_renderer* r, float* dst, size_t n) { return acc_copy(r, dst, r ? r->d_acc : nullptr, n, hipMemcpyDeviceToHost); }
+int cl2_write_accumulators_packed(cl2_renderer* r, const float* src, size_t n) { return acc_copy(r, r ? r->d_acc : nullptr, src, n, hipMemcpyHostToDevice); }
+int cl2_copy_accumulators_to_device(cl2_renderer* r, void* dst, size_t n) { return acc_copy(r, dst, r ? r->d_acc : nullptr, n, hipMemcpyDeviceToDevice); }
+int cl2_copy_accumulators_from_device(cl2_renderer* r, const void* src, size_t n) { return acc_copy(r, r ? r->d_acc : nullptr, src, n, hipMemcpyDeviceToDevice); }
+
+int cl2_set_profiling(cl2_renderer* r, int on) { if (!r) return CL2_E_INVALID; r->profiling = on != 0; return CL2_OK; }
+int cl2_set_counting(cl2_renderer* r, int on) { if (!r) return CL2_E_INVALID; r->counting = on != 0; return CL2_OK; }
+
+int cl2_read_counters(cl2_renderer* r, cl2_counters* out) {
+    if (!r || !out) return CL2_E_INVALID;
+    HIP_TRY(r, hipSetDevice(r->device));
+    TRY(drain(r));
+    Stats s;
+    HIP_TRY(r, hipMemcpy(&s, r->d_stats, sizeof s, hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof *out);
+    out->rays = s.rays; out->conn_rays = s.conn_rays; out->box_tests = s.box_tests; out->tri_tests = s.tri_tests;
+    out->counted_rays = s.counted_rays;
+    out->samples = r->samples;
+    out->ms_generate = r->ms[ST_GENERATE]; out->ms_traverse_paths = r->ms[ST_TRAVERSE_PATHS]; out->ms_bounce = r->ms[ST_BOUNCE];
+    out->ms_connect_setup = r->ms[ST_CONNECT_SETUP]; out->ms_traverse_conn = r->ms[ST_TRAVERSE_CONN];
+    out->ms_connect_resolve = r->ms[ST_CONNECT_RESOLVE]; out->ms_finalize = r->ms[ST_FINALIZE]; out->ms_accumulate = r->ms[ST_ACCUMULATE];
+    out->launches_traverse_paths = r->launches_tp; out->launches_traverse_conn = r->launches_tc;
+    out->rays_traverse_paths = s.rays - s.conn_rays; out->rays_traverse_conn = s.conn_rays;
+    return CL2_OK;
+}
+
+int cl2_reset_counters(cl2_renderer* r) {
+    if (!r) return CL2_E_INVALID;
+    HIP_TRY(r, hipSetDevice(r->device));
+    TRY(drain(r));
+    HIP_TRY(r, hipMemset(r->d_stats, 0, sizeof(Stats)));
+    for (double& m : r->ms) m = 0.0;
+    r->launches_tp = r->launches_tc = 0;
+    return CL2_OK;
+}
+
+int cl2_export_rays(cl2_renderer* r, int which, void* out, size_t n_records) {
+    STAGE_PROLOGUE(r);
+    if (!out || (which != CL2_LIGHT && which != CL2_CAMERA) || n_records != (size_t)r->B) return fail(r, CL2_E_INVALID, "bad export_rays arguments");
+    RayRec* d = nullptr;
+    TRY(dev_alloc(r, &d, (size_t)r->B));
+    hipLaunchKernelGGL(k_export_rays, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->pb[which], which == CL2_CAMERA ? 1 : 0, d);
+    int rc = drain(r);
+    if (rc == CL2_OK && hipMemcpy(out, d, (size_t)r->B * sizeof(RayRec), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(r, CL2_E_HIP, "export copy failed");
+    dev_free(r, d);
+    return rc;
+}
+
+int cl2_export_paths(cl2_renderer* r, int which, void* out, size_t n_records) {
+    STAGE_PROLOGUE(r);
+    if (!out || (which != CL2_LIGHT && which != CL2_CAMERA) || n_records != (size_t)r->B) return fail(r, CL2_E_INVALID, "bad export_paths arguments");
+    unsigned char* d = nullptr;
+    TRY(dev_alloc(r, &d, (size_t)r->B * 1040));
+    hipLaunchKernelGGL(k_export_paths, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->pb[which], which == CL2_CAMERA ? 1 : 0, d);
+    int rc = drain(r);
+    if (rc == CL2_OK && hipMemcpy(out, d, (size_t)r->B * 1040, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(r, CL2_E_HIP, "export copy failed");
+    dev_free(r, d);
+    return rc;
+}
+
+int cl2_export_aggregators(cl2_renderer* r, void* out, size_t n_records) {
+    STAGE_PROLOGUE(r);
+    if (!out || n_records != (size_t)r->B) return fail(r, CL2_E_INVALID, "bad export_aggregators arguments");
+    float* d = nullptr;
+    TRY(dev_alloc(r, &d, (size_t)r->B * 32));
+    hipLaunchKernelGGL(k_export_aggregators, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->d_agg, d);
+    int rc = drain(r);
+    if (rc == CL2_OK && hipMemcpy(out, d, (size_t)r->B * 128, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(r, CL2_E_HIP, "export copy failed");
+    dev_free(r, d);
+    return rc;
+}
+
+int cl2_export_sample_images(cl2_renderer* r, float* fin4, float* light4, float* sw, float* uni4, size_t n_pixels) {
+    STAGE_PROLOGUE(r);
+    if (n_pixels != (size_t)r->B) return fail(r, CL2_E_INVALID, "n_pixels must equal W*H");
+    TRY(drain(r));
+    const size_t B = r->B;
+    if (fin4) HIP_TRY(r, hipMemcpy(fin4, r->d_finalized, B * sizeof(float4), hipMemcpyDeviceToHost));
+    if (light4) HIP_TRY(r, hipMemcpy(light4, r->d_light_image, B * sizeof(float4), hipMemcpyDeviceToHost));
+    if (sw) HIP_TRY(r, hipMemcpy(sw, r->d_sample_w, B * sizeof(float), hipMemcpyDeviceToHost));
+    if (uni4) HIP_TRY(r, hipMemcpy(uni4, r->d_uni, B * sizeof(float4), hipMemcpyDeviceToHost));
+    return CL2_OK;
+}
+
+int cl2_probe_traverse(cl2_renderer* r, const void* rays_v, size_t n_rays, int32_t* best_i, float* best_t, float* u, float* v) {
+    STAGE_PROLOGUE(r);
+    if (!rays_v || !best_i || !best_t || !u || !v) return fail(r, CL2_E_INVALID, "NULL probe array");
+    if (n_rays == 0) return CL2_OK;
+    if (n_rays > (size_t)1 << 30) return fail(r, CL2_E_INVALID, "too many probe rays");
+    const RayRec* rays = static_cast<const RayRec*>(rays_v);
+    std::vector<float4> o(n_rays), d(n_rays), h(n_rays);
+    for (size_t i = 0; i < n_rays; i++) {
+        o[i] = make_float4(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2], 0.0f);
+        d[i] = make_float4(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2], 0.0f);
+    }
+    float4 *d_o = nullptr, *d_d = nullptr, *d_h = nullptr;
+    unsigned* d_n = nullptr;
+    int rc = dev_alloc(r, &d_o, n_rays);
+    if (rc == CL2_OK) rc = dev_alloc(r, &d_d, n_rays);
+    if (rc == CL2_OK) rc = dev_alloc(r, &d_h, n_rays);
+    if (rc == CL2_OK) rc = dev_alloc(r, &d_n, (size_t)1);
+    if (rc == CL2_OK) {
+        const unsigned n = (unsigned)n_rays;
+        bool ok = hipMemcpy(d_o, o.data(), n_rays * sizeof(float4), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(d_d, d.data(), n_rays * sizeof(float4), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(d_n, &n, sizeof n, hipMemcpyHostToDevice) == hipSuccess;
+        if (!ok) rc = fail(r, CL2_E_HIP, "probe upload failed");
+    }
+    if (rc == CL2_OK) {
+        if (r->counting)
+            hipLaunchKernelGGL(k_traverse_paths<true>, dim3(grid_for(n_rays)), dim3(BLOCK), 0, r->stream, r->bvh, (const int*)nullptr, d_n, d_o, d_d, d_h, r->d_stats);
+        else
+            hipLaunchKernelGGL(k_traverse_paths<false>, dim3(grid_for(n_rays)), dim3(BLOCK), 0, r->stream, r->bvh, (const int*)nullptr, d_n, d_o, d_d, d_h, r->d_stats);
+        rc = drain(r);
+    }
+    if (rc == CL2_OK && hipMemcpy(h.data(), d_h, n_rays * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(r, CL2_E_HIP, "probe download failed");
+    if (rc == CL2_OK)
+        for (size_t i = 0; i < n_rays; i++) {
+            std::memcpy(&best_i[i], &h[i].x, 4);
+            best_t[i] = h[i].y; u[i] = h[i].z; v[i] = h[i].w;
+        }
+    dev_free(r, d_o); dev_free(r, d_d); dev_free(r, d_h); dev_free(r, d_n);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,271 @@
+"""`Renderer`: the reference's render driver (src/renderer.py:16-352) on top of the HIP library.
+
+Same constructor, stage-method names, `samples` counter, image properties and accumulator
+attributes as the reference class, so callers written against it (`render.py:26-37`,
+`movie.py:39-44`) work unchanged.  Differences, all deliberate:
+
+* device state and accumulators live in the library (SoA in HBM); the accumulator attributes
+  are read back on access instead of being updated on the host every sample;
+* the RNG buffer is explicit: `Renderer(scene, seeds=...)` / `set_seeds()` (the reference seeds
+  from unseeded `np.random.randint`, renderer.py:86-87, and is therefore not reproducible);
+* `run_samples(n)` runs n iterations of the pipeline without returning to the host;
+* `gather_light_image` is a no-op synchronisation point: the t=1 light-image splat happens in
+  `join_paths` with float atomics (the reference's 300-launch bitonic sort + host bincount,
+  renderer.py:212-250, has no counterpart);
+* multi-GPU sample splitting: `reduce_accumulators()` sums the accumulators of all ranks of a
+  `torch.distributed` process group (RCCL over xGMI on GPUs).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+from ._native import RendererError, Counters, ptr
+from . import struct_types as st
+from .camera import tone_map
+from .constants import timed, MAX_PATH_LENGTH  # noqa: F401
+
+LIGHT, CAMERA = 0, 1
+
+
+def make_seeds(batch_size, seed=20240928, rank=0):
+    """Seed buffer of SURVEY.md §8(d): `RandomState(seed+rank).randint(0, 2**32, (B,2), uint32)`
+    -- the call shape of renderer.py:86-87 -- with zeros (xorshift's fixed point) replaced by 1."""
+    s = np.random.RandomState(seed + rank).randint(0, 2 ** 32, size=(batch_size, 2), dtype=np.uint32)
+    s[s == 0] = 1
+    return s
+
+
+def next_power_of_two(n):
+    return 1 << (n - 1).bit_length() if n > 0 else 1
+
+
+class Renderer:
+    def __init__(self, scene, kernel_path=None, seeds=None, device=0):
+        # kernel_path is accepted for signature compatibility (the reference JIT-compiles
+        # trace.metal from it, renderer.py:27-29); the HIP kernels are precompiled.
+        self._h = C.c_void_p()
+        self._L = _native.lib()
+        self.scene = scene
+        self.device = device
+        self.pixel_width, self.pixel_height = scene.pixel_width, scene.pixel_height
+        self.batch_size = scene.pixel_width * scene.pixel_height
+        rc = self._L.cl2_create(int(device), int(scene.pixel_width), int(scene.pixel_height), C.byref(self._h))
+        if rc != 0:
+            msg = self._L.cl2_last_error(None)
+            self._h = C.c_void_p()
+            raise RendererError(f"cl2_create failed ({rc}): {msg.decode() if msg else ''}")
+        self.samples = 0
+        self.upload_scene(scene)
+        self.set_seeds(make_seeds(self.batch_size) if seeds is None else seeds)
+
+    # ---- plumbing ----
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._L.cl2_last_error(self._h)
+            raise RendererError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def upload_scene(self, scene):
+        if hasattr(scene, "validate"):
+            scene.validate()
+        def rec(a, dt):
+            a = np.ascontiguousarray(a)
+            if a.dtype.itemsize != dt.itemsize:
+                raise RendererError(f"scene array has itemsize {a.dtype.itemsize}, expected {dt.itemsize}")
+            return a.reshape(-1)
+        boxes, tris = rec(scene.boxes, st.Box), rec(scene.triangles, st.Triangle)
+        mats, cam = rec(scene.materials, st.Material), rec(scene.camera, st.Camera)
+        ltris = rec(scene.light_triangles, st.Triangle)
+        areas = np.ascontiguousarray(scene.light_surface_areas, dtype=np.float32).reshape(-1)
+        lidx = np.ascontiguousarray(scene.light_triangle_indices, dtype=np.int32).reshape(-1)
+        n_light = int(np.asarray(scene.light_counts).reshape(-1)[0])
+        if not (len(ltris) == len(areas) == len(lidx) == n_light):
+            raise RendererError("light arrays disagree in length")
+        self._check(self._L.cl2_upload_scene(self._h, ptr(boxes), len(boxes), ptr(tris), len(tris), ptr(mats), len(mats),
+                                             ptr(cam), ptr(ltris), ptr(areas), ptr(lidx), n_light), "cl2_upload_scene")
+
+    def set_seeds(self, seeds):
+        s = np.ascontiguousarray(seeds, dtype=np.uint32)
+        if s.size != 2 * self.batch_size:
+            raise RendererError(f"seed buffer needs {2 * self.batch_size} uint32 words, got {s.size}")
+        self._check(self._L.cl2_set_seeds(self._h, ptr(s), C.c_size_t(s.size)), "cl2_set_seeds")
+
+    def get_random_buffer(self):
+        s = np.empty((self.batch_size, 2), dtype=np.uint32)
+        self._check(self._L.cl2_get_seeds(self._h, ptr(s), C.c_size_t(s.size)), "cl2_get_seeds")
+        return s
+
+    # ---- the eight stages of run_sample (renderer.py:113-278) ----
+    @timed
+    def make_light_rays(self):
+        self._check(self._L.cl2_make_light_rays(self._h), "make_light_rays")
+
+    @timed
+    def make_camera_rays(self):
+        self._check(self._L.cl2_make_camera_rays(self._h), "make_camera_rays")
+
+    @timed
+    def trace_light_rays(self):
+        self._check(self._L.cl2_trace_light_rays(self._h), "trace_light_rays")
+
+    @timed
+    def trace_camera_rays(self):
+        self._check(self._L.cl2_trace_camera_rays(self._h), "trace_camera_rays")
+
+    @timed
+    def join_paths(self):
+        self._check(self._L.cl2_join_paths(self._h), "join_paths")
+
+    @timed
+    def finalize_samples(self):
+        self._check(self._L.cl2_finalize_samples(self._h), "finalize_samples")
+
+    @timed
+    def gather_light_image(self):
+        self._check(self._L.cl2_gather_light_image(self._h), "gather_light_image")
+
+    @timed
+    def process_images(self):
+        self._check(self._L.cl2_process_images(self._h), "process_images")
+
+    @timed
+    def run_sample(self):
+        self.run_samples(1)
+
+    def run_samples(self, n):
+        self._check(self._L.cl2_run_samples(self._h, int(n)), "run_samples")
+        self.samples += int(n)
+
+    # ---- accumulators (renderer.py:41-45) ----
+    def read_accumulators(self):
+        H, W, B = self.pixel_height, self.pixel_width, self.batch_size
+        img = np.empty((H, W, 3), np.float32)
+        wts = np.empty((H, W, 1), np.float32)
+        cnt = np.empty((H, W, 1), np.int32)
+        uni = np.empty((H, W, 3), np.float32)
+        self._check(self._L.cl2_read_accumulators(self._h, ptr(img), ptr(wts), ptr(cnt), ptr(uni), C.c_size_t(B)),
+                    "cl2_read_accumulators")
+        return img, wts, cnt, uni
+
+    summed_image = property(lambda self: self.read_accumulators()[0])
+    summed_sample_weights = property(lambda self: self.read_accumulators()[1])
+    summed_sample_counts = property(lambda self: self.read_accumulators()[2])
+    unidirectional_image_buffer = property(lambda self: self.read_accumulators()[3])
+
+    def reset_accumulators(self):
+        self._check(self._L.cl2_reset_accumulators(self._h), "cl2_reset_accumulators")
+        self.samples = 0
+
+    @property
+    def radiance(self):
+        """`summed_image / summed_sample_weights`, scrubbed -- the reference image before tone
+        mapping (renderer.py:295-297); float32 (H,W,3), BGR."""
+        img, wts, _, _ = self.read_accumulators()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.nan_to_num(img / wts, neginf=0, posinf=0)
+
+    @property
+    def unidirectional_radiance(self):
+        _, _, cnt, uni = self.read_accumulators()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.nan_to_num(uni / cnt, neginf=0, posinf=0)
+
+    @property
+    def image(self):
+        return tone_map(self.radiance, exposure=4.0)
+
+    @property
+    def unweighted_image(self):
+        return tone_map(np.nan_to_num(self.read_accumulators()[0], neginf=0, posinf=0), exposure=4.0)
+
+    @property
+    def unidirectional_image(self):
+        return tone_map(self.unidirectional_radiance, exposure=4.0)
+
+    # ---- multi-GPU sample split: one sum-reduce of the packed accumulators ----
+    def packed_accumulators(self):
+        a = np.empty(8 * self.batch_size, np.float32)
+        self._check(self._L.cl2_read_accumulators_packed(self._h, ptr(a), C.c_size_t(a.size)), "read_packed")
+        return a
+
+    def load_packed_accumulators(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+        self._check(self._L.cl2_write_accumulators_packed(self._h, ptr(a), C.c_size_t(a.size)), "write_packed")
+
+    def reduce_accumulators(self, group=None):
+        """All-reduce (sum) the accumulators over the ranks of a torch.distributed group.  On GPUs
+        the message stays in HBM (RCCL); with a CPU backend (gloo) it goes through the host."""
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return
+        n = 8 * self.batch_size
+        if dist.get_backend(group) == "nccl":
+            t = torch.empty(n, dtype=torch.float32, device=f"cuda:{self.device}")
+            self._check(self._L.cl2_copy_accumulators_to_device(self._h, C.c_void_p(t.data_ptr()), C.c_size_t(n)), "acc->dev")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            torch.cuda.synchronize(self.device)
+            self._check(self._L.cl2_copy_accumulators_from_device(self._h, C.c_void_p(t.data_ptr()), C.c_size_t(n)), "dev->acc")
+        else:
+            t = torch.from_numpy(self.packed_accumulators())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            self.load_packed_accumulators(t.numpy())
+
+    # ---- counters / profiling ----
+    def set_profiling(self, on=True):
+        self._check(self._L.cl2_set_profiling(self._h, int(bool(on))), "set_profiling")
+
+    def set_counting(self, on=True):
+        self._check(self._L.cl2_set_counting(self._h, int(bool(on))), "set_counting")
+
+    def counters(self):
+        c = Counters()
+        self._check(self._L.cl2_read_counters(self._h, C.byref(c)), "read_counters")
+        return c.as_dict()
+
+    def reset_counters(self):
+        self._check(self._L.cl2_reset_counters(self._h), "reset_counters")
+
+    # ---- debug exports in the reference's AoS layouts ----
+    def export_rays(self, which):
+        out = np.zeros(self.batch_size, dtype=st.Ray)
+        self._check(self._L.cl2_export_rays(self._h, int(which), ptr(out), C.c_size_t(len(out))), "export_rays")
+        return out
+
+    def export_paths(self, which):
+        out = np.zeros(self.batch_size, dtype=st.Path)
+        self._check(self._L.cl2_export_paths(self._h, int(which), ptr(out), C.c_size_t(len(out))), "export_paths")
+        return out
+
+    def export_aggregators(self):
+        out = np.zeros(self.batch_size, dtype=st.WeightAggregator)
+        self._check(self._L.cl2_export_aggregators(self._h, ptr(out), C.c_size_t(len(out))), "export_aggregators")
+        return out
+
+    def export_sample_images(self):
+        B = self.batch_size
+        fin, light, uni = (np.zeros((B, 4), np.float32) for _ in range(3))
+        sw = np.zeros(B, np.float32)
+        self._check(self._L.cl2_export_sample_images(self._h, ptr(fin), ptr(light), ptr(sw), ptr(uni), C.c_size_t(B)),
+                    "export_sample_images")
+        return dict(finalized=fin, light=light, sample_weights=sw, unidirectional=uni)
+
+    def probe_traverse(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=st.Ray)
+        n = len(rays)
+        bi, bt = np.empty(n, np.int32), np.empty(n, np.float32)
+        u, v = np.empty(n, np.float32), np.empty(n, np.float32)
+        self._check(self._L.cl2_probe_traverse(self._h, ptr(rays), C.c_size_t(n), ptr(bi), ptr(bt), ptr(u), ptr(v)),
+                    "probe_traverse")
+        return bi, bt, u, v
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.cl2_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,131 @@
+/* clive2_amd.h -- C ABI of the MI355X bidirectional path tracer (libclive2_amd.so).
+ *
+ * Drop-in boundary for the reference's Metal dispatch.  In pmclaugh/Clive2 the class
+ * `Renderer` (src/renderer.py:16-352) owns ~25 `metalcompute` buffers and launches the eight
+ * kernels of src/trace.metal through `dev.kernel(text).function(name)(n, *buffers)`
+ * (src/renderer.py:27-37, :113-250); `create_scene` uploads nine scene buffers with
+ * `dev.buffer(...)` (src/scene.py:74-89).  The entry points below are what a ctypes / cffi
+ * binding of that class binds instead: plain pointers and sizes, no Python, no torch types.
+ *
+ *   - All record pointers use the reference's AoS layouts (src/struct_types.py:4-85):
+ *     Box 48 B, Triangle 128 B, Material 48 B, Camera 112 B, Ray 128 B, Path 1040 B.
+ *   - Every function returns 0 on success or a negative CL2_E_* code; cl2_last_error() returns
+ *     a message for the last failure on that handle (replaces `metalcompute.error`,
+ *     src/render.py:39).  No HIP failure aborts the process.
+ *   - The library owns all device memory.  Host arrays passed in are copied during the call;
+ *     outputs are written into caller-allocated arrays whose element counts are checked.
+ *   - Calls are synchronous (they return after the stream has drained) and not re-entrant per
+ *     handle; use one handle per GPU, one process (or thread) per handle.
+ */
+#ifndef CLIVE2_AMD_H
+#define CLIVE2_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cl2_renderer cl2_renderer;
+
+enum {
+    CL2_OK = 0,
+    CL2_E_INVALID = -1,      /* bad argument / scene failed validation */
+    CL2_E_HIP = -2,          /* HIP runtime error (see cl2_last_error) */
+    CL2_E_STATE = -3,        /* call sequence error (e.g. no scene uploaded) */
+    CL2_E_NOMEM = -4
+};
+
+/* Which subpath / ray buffer: reference `light_ray_buffer` / `camera_ray_buffer`,
+ * `out_light_paths` / `out_camera_paths` (src/renderer.py:51-52, :58, :79). */
+enum { CL2_LIGHT = 0, CL2_CAMERA = 1 };
+
+/* Stage timers and tallies accumulated since cl2_reset_counters (replaces the reference's
+ * `@timed` prints, src/constants.py:39-49).  One "ray" = one closest-hit BVH query =
+ * one call of traverse_bvh (src/trace.metal:144).  Times are GPU milliseconds measured
+ * with HIP events on the renderer's stream; they are only collected while profiling is on. */
+typedef struct {
+    uint64_t rays;            /* all closest-hit queries */
+    uint64_t conn_rays;       /* the subset issued by the connection stage */
+    uint64_t box_tests;       /* node tests   (only counted while counting is on) */
+    uint64_t tri_tests;       /* triangle tests (only counted while counting is on) */
+    uint64_t counted_rays;    /* rays traced while counting was on */
+    uint64_t samples;         /* completed run_sample iterations */
+    double ms_generate, ms_traverse_paths, ms_bounce, ms_connect_setup, ms_traverse_conn,
+           ms_connect_resolve, ms_finalize, ms_accumulate;
+    uint64_t launches_traverse_paths, launches_traverse_conn;
+    uint64_t rays_traverse_paths, rays_traverse_conn;   /* rays inside the timed launches */
+} cl2_counters;
+
+/* -- lifetime: replaces metalcompute.Device() + Renderer.__init__/__del__
+ *    (src/scene.py:29, src/renderer.py:17-84, :318-352) -- */
+int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_renderer** out);
+void cl2_destroy(cl2_renderer* r);
+const char* cl2_last_error(const cl2_renderer* r);   /* r may be NULL: error of the last failed cl2_create */
+int cl2_abi_version(void);
+
+/* -- scene upload: replaces the nine dev.buffer(...) uploads of create_scene
+ *    (src/scene.py:74-89).  Arrays are in the reference layouts; light_* are the emitter
+ *    triangle list, its areas and its indices into `triangles`. -- */
+int cl2_upload_scene(cl2_renderer* r,
+                     const void* boxes, int n_boxes,
+                     const void* triangles, int n_triangles,
+                     const void* materials, int n_materials,
+                     const void* camera,
+                     const void* light_triangles, const float* light_surface_areas,
+                     const int32_t* light_triangle_indices, int light_count);
+
+/* -- RNG state: the (batch,2) uint32 xorshift buffer of src/renderer.py:54,86-87 -- */
+int cl2_set_seeds(cl2_renderer* r, const uint32_t* seeds, size_t n_words);
+int cl2_get_seeds(cl2_renderer* r, uint32_t* seeds, size_t n_words);
+
+/* -- the per-sample pipeline.  The eight stage calls mirror Renderer's stage methods
+ *    (src/renderer.py:113-278) for stage-level parity work; cl2_run_samples(n) is
+ *    n x Renderer.run_sample (src/renderer.py:281-291) without returning to the host. -- */
+int cl2_make_light_rays(cl2_renderer* r);
+int cl2_make_camera_rays(cl2_renderer* r);
+int cl2_trace_light_rays(cl2_renderer* r);
+int cl2_trace_camera_rays(cl2_renderer* r);
+int cl2_join_paths(cl2_renderer* r);
+int cl2_finalize_samples(cl2_renderer* r);
+int cl2_gather_light_image(cl2_renderer* r);
+int cl2_process_images(cl2_renderer* r);
+int cl2_run_samples(cl2_renderer* r, int n);
+
+/* -- accumulators: Renderer.summed_image / summed_sample_weights / summed_sample_counts /
+ *    unidirectional_image_buffer (src/renderer.py:41-45).  Any pointer may be NULL. -- */
+int cl2_read_accumulators(cl2_renderer* r, float* summed_image /*H*W*3*/, float* summed_sample_weights /*H*W*/,
+                          int32_t* summed_sample_counts /*H*W*/, float* unidirectional /*H*W*3*/, size_t n_pixels);
+int cl2_reset_accumulators(cl2_renderer* r);
+/* packed planar form [8][H*W] = image b,g,r | weights | unidirectional b,g,r | counts(float):
+ * the message of the multi-GPU sum-reduce.  *_device take DEVICE pointers (e.g. a torch tensor's
+ * data_ptr()) so RCCL can reduce without a host round trip. */
+int cl2_read_accumulators_packed(cl2_renderer* r, float* host_dst, size_t n_floats);
+int cl2_write_accumulators_packed(cl2_renderer* r, const float* host_src, size_t n_floats);
+int cl2_copy_accumulators_to_device(cl2_renderer* r, void* device_dst, size_t n_floats);
+int cl2_copy_accumulators_from_device(cl2_renderer* r, const void* device_src, size_t n_floats);
+
+/* -- counters / profiling -- */
+int cl2_set_profiling(cl2_renderer* r, int on);     /* HIP-event timers per stage */
+int cl2_set_counting(cl2_renderer* r, int on);      /* node / triangle test tallies in the traversal kernels */
+int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
+int cl2_reset_counters(cl2_renderer* r);
+
+/* -- debug exports in the reference's AoS layouts (stage-level parity) -- */
+int cl2_export_rays(cl2_renderer* r, int which, void* out_rays, size_t n_records);        /* Ray[batch]  */
+int cl2_export_paths(cl2_renderer* r, int which, void* out_paths, size_t n_records);      /* Path[batch] */
+int cl2_export_aggregators(cl2_renderer* r, void* out, size_t n_records);                 /* 128-B stride */
+/* per-sample images: finalized_samples (float4), out_light_image rgb + summed light weight (float4),
+ * sample_weights (K6 value only), out_camera_image (float4).  Any pointer may be NULL. */
+int cl2_export_sample_images(cl2_renderer* r, float* finalized4, float* light4, float* sample_weights,
+                             float* unidirectional4, size_t n_pixels);
+/* closest-hit probe: n rays as Ray records -> (triangle, t, u, v) per ray; exercises the traversal
+ * kernel alone (src/trace.metal:144-176). */
+int cl2_probe_traverse(cl2_renderer* r, const void* rays, size_t n_rays, int32_t* best_i, float* best_t,
+                       float* u, float* v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

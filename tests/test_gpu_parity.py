@@ -1,0 +1,140 @@
+"""GPU <-> oracle parity, stage by stage, through the C ABI (ctypes -> libclive2_amd.so).
+
+Bar: BIT-EXACT for everything that is a deterministic function of the inputs (rays, closest
+hits, subpaths, RNG state, filter aggregators, finalized samples, unidirectional estimate);
+rtol 1e-5 where float atomics reorder a sum (the t=1 light-image splat and what it feeds).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LIGHT, CAMERA = 0, 1
+
+
+def _pair(scene, orc, seeds=None):
+    from clive2_amd.renderer import Renderer, make_seeds
+    B = scene.pixel_width * scene.pixel_height
+    seeds = make_seeds(B) if seeds is None else seeds
+    return Renderer(scene, seeds=seeds), orc.OracleRenderer(scene, seeds=seeds)
+
+
+def _diff_fields(got, ref, dt):
+    bad = []
+    for name in dt.names:
+        if got[name].tobytes() != ref[name].tobytes():
+            bad.append(name)
+    return bad
+
+
+def _run_to_paths(r, o):
+    for x in (r, o):
+        x.make_light_rays(); x.make_camera_rays(); x.trace_light_rays(); x.trace_camera_rays()
+
+
+def _run_rest(r, o):
+    for x in (r, o):
+        x.join_paths(); x.finalize_samples(); x.gather_light_image(); x.process_images()
+
+
+@pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
+def test_generated_rays_bit_exact(scene_name, request, oracle_mod):
+    from clive2_amd import struct_types as st
+    scene = request.getfixturevalue(scene_name)
+    r, o = _pair(scene, oracle_mod)
+    r.make_light_rays(); o.make_light_rays()
+    assert _diff_fields(r.export_rays(LIGHT), o.light_ray_buffer, st.Ray) == []
+    r.make_camera_rays(); o.make_camera_rays()
+    assert _diff_fields(r.export_rays(CAMERA), o.camera_ray_buffer, st.Ray) == []
+    assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
+
+
+@pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
+def test_closest_hit_bit_exact(scene_name, request, oracle_mod):
+    """traverse_bvh alone: camera rays, light rays and axis-parallel rays (inv_direction = +-inf)."""
+    from clive2_amd import struct_types as st
+    scene = request.getfixturevalue(scene_name)
+    r, o = _pair(scene, oracle_mod)
+    o.make_light_rays(); o.make_camera_rays()
+    axis = np.zeros(6 * 64, dtype=st.Ray)
+    rng = np.random.RandomState(5)
+    axis["origin"][:, :3] = rng.uniform(-9, 9, size=(len(axis), 3)).astype(np.float32)
+    axis["origin"][::4, 0] = -10.0        # start exactly on a slab plane: 0 * inf = NaN in the box test
+    for k in range(6):
+        d = np.zeros(3, np.float32); d[k % 3] = 1.0 if k < 3 else -1.0
+        axis["direction"][k::6, :3] = d
+    with np.errstate(divide="ignore"):
+        axis["inv_direction"][:, :3] = np.float32(1.0) / axis["direction"][:, :3]
+    rays = np.concatenate([o.camera_ray_buffer, o.light_ray_buffer, axis])
+    bi, bt, u, v = r.probe_traverse(rays)
+    rbi, rbt, ru, rv, _ = oracle_mod.traverse(rays, scene.boxes, scene.triangles)
+    assert np.array_equal(bi, rbi)
+    hit = rbi >= 0
+    assert hit.sum() > 0.9 * len(o.camera_ray_buffer)
+    assert bt[hit].tobytes() == rbt[hit].tobytes()
+    assert u[hit].tobytes() == ru[hit].tobytes() and v[hit].tobytes() == rv[hit].tobytes()
+
+
+@pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
+def test_subpaths_bit_exact(scene_name, request, oracle_mod):
+    from clive2_amd import struct_types as st
+    scene = request.getfixturevalue(scene_name)
+    r, o = _pair(scene, oracle_mod)
+    _run_to_paths(r, o)
+    for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
+        got = r.export_paths(which)
+        assert np.array_equal(got["length"], ref["length"])
+        assert _diff_fields(got["rays"], ref["rays"], st.Ray) == []
+        assert got.tobytes() == ref.tobytes()
+    assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
+    c = r.counters()
+    assert c["rays"] == o.rays_traced
+    if scene_name == "glass_scene":    # glass must actually be exercised: some paths end early
+        assert (o.out_camera_paths["length"] < 6).any()
+
+
+@pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
+def test_connection_stage(scene_name, request, oracle_mod):
+    scene = request.getfixturevalue(scene_name)
+    r, o = _pair(scene, oracle_mod)
+    _run_to_paths(r, o)
+    r.join_paths(); o.join_paths()
+    agg = r.export_aggregators()
+    for f in ("weights", "total_contribution", "contrib_weight_sum"):
+        assert agg[f].tobytes() == o.weight_aggregators[f].tobytes(), f
+    assert r.counters()["rays"] == o.rays_traced          # same number of closest-hit queries
+    r.finalize_samples(); o.finalize_samples()
+    imgs = r.export_sample_images()
+    assert imgs["finalized"][:, :3].tobytes() == o.finalized_samples[:, :3].tobytes()
+    assert imgs["sample_weights"].tobytes() == o.sample_weights.tobytes()
+    assert imgs["unidirectional"].tobytes() == o.out_camera_image.tobytes()
+    r.gather_light_image(); o.gather_light_image()
+    # the light image is a sum in a different order (atomics vs sorted segments)
+    np.testing.assert_allclose(imgs["light"][:, :3], o.out_light_image[:, :3], rtol=2e-5, atol=1e-9)
+    assert (o.out_light_image[:, :3] > 0).any()
+    r.process_images(); o.process_images()
+    img, wts, cnt, uni = r.read_accumulators()
+    np.testing.assert_allclose(img, o.summed_image, rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(wts, o.summed_sample_weights, rtol=2e-5, atol=1e-9)
+    assert np.array_equal(cnt, o.summed_sample_counts)
+    assert uni.tobytes() == o.unidirectional_image_buffer.tobytes()
+
+
+@pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
+def test_multi_sample_accumulation(scene_name, request, oracle_mod):
+    """run_samples(n) == n x run_sample of the oracle: RNG state carried across samples, accumulators."""
+    scene = request.getfixturevalue(scene_name)
+    r, o = _pair(scene, oracle_mod)
+    r.run_samples(4)
+    for _ in range(4):
+        o.run_sample()
+    assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
+    img, wts, cnt, uni = r.read_accumulators()
+    np.testing.assert_allclose(img, o.summed_image, rtol=5e-5, atol=1e-8)
+    np.testing.assert_allclose(wts, o.summed_sample_weights, rtol=5e-5, atol=1e-8)
+    assert (cnt == 4).all()
+    np.testing.assert_allclose(uni, o.unidirectional_image_buffer, rtol=1e-6, atol=0)
+    # north-star metric: per-pixel L2 of the radiance image < 1e-3
+    l2 = np.sqrt(((r.radiance - o.radiance) ** 2).sum(axis=2))
+    assert l2.max() < 1e-3
+    assert r.counters()["rays"] == o.rays_traced
