@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: Mrays/s (whole job) on the 1080p Cornell box, N x MI355X.
+
+One "step" = one sample of the full BDPT pipeline (Renderer.run_sample: light + camera subpaths,
+all (t,s) connections, light splat, filter, accumulate) over the whole 1920x1080 frame on every
+rank.  Ranks are weak-scaled (each integrates its own samples of the replicated scene, own seed
+buffer); the accumulators are summed once with an RCCL all-reduce inside the timed region.
+One "ray" = one closest-hit BVH query; rays are counted on the device.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--width 1920 --height 1080]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant traversal kernel with the
+algorithmic bytes of SURVEY.md §8(d): B_ray = 48 + 32*N_node + 36*N_tri, N_node/N_tri measured by
+device counters in a separate (untimed) counting pass, kernel time from HIP events recorded on
+the renderer's stream during the timed region.  `cpu_baseline` times the C oracle (the CPU
+restatement of the reference's kernels, OpenMP over host cores) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(width, height, samples):
+    """Oracle (kind 'port'): the CPU restatement of trace.metal's kernels + renderer.py's host glue,
+    timed end to end on this host's cores.  Checker code used as the reported baseline only."""
+    import numpy as np
+    import clive2_amd as c2
+    from oracle import oracle as orc
+    orc.build()
+    scene = c2.create_scene_from_preset("empty", width, height)
+    o = orc.OracleRenderer(scene, seeds=orc.make_seeds(width * height))
+    t0 = time.perf_counter()
+    for _ in range(samples):
+        o.run_sample()
+    dt = time.perf_counter() - t0
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    omp = os.environ.get("OMP_NUM_THREADS")
+    threads = int(omp) if omp else cores
+    return {"value": round(o.rays_traced / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"Cornell box {width}x{height}, {samples} sample(s) of the full BDPT pipeline "
+                      f"({o.rays_traced} rays, {dt:.1f} s; C oracle, OpenMP)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-width", type=int, default=960)
+    ap.add_argument("--cpu-height", type=int, default=540)
+    ap.add_argument("--cpu-samples", type=int, default=1)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    import clive2_amd as c2
+    from clive2_amd.renderer import Renderer, make_seeds
+
+    W, H = args.width, args.height
+    scene = c2.create_scene_from_preset("empty", W, H)
+    r = Renderer(scene, seeds=make_seeds(W * H, rank=rank), device=local_rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed: warm-up (also the counting pass that measures N_node / N_tri per ray)
+    r.set_counting(True)
+    r.run_samples(max(args.warmup, 1))
+    cw = r.counters()
+    n_node = cw["box_tests"] / max(cw["counted_rays"], 1)
+    n_tri = cw["tri_tests"] / max(cw["counted_rays"], 1)
+    r.set_counting(False)
+    r.reset_counters()
+    r.reset_accumulators()
+    r.set_profiling(True)
+
+    barrier()
+    t0 = time.perf_counter()
+    r.run_samples(args.steps)
+    r.reduce_accumulators()
+    barrier()
+    dt = time.perf_counter() - t0
+
+    c = r.counters()
+    rays_local = c["rays"]
+    if world > 1:
+        t = torch.tensor([float(rays_local), dt], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        rays_total, dt = t[0].item(), tmax[1].item()
+    else:
+        rays_total = float(rays_local)
+
+    if rank == 0:
+        img, wts, cnt, _ = r.read_accumulators()
+        assert np.isfinite(img).all() and (cnt == args.steps * world).all(), "accumulators corrupt"
+        b_ray = 48.0 + 32.0 * n_node + 36.0 * n_tri
+        stages = {k[3:]: round(c[k], 3) for k in c if k.startswith("ms_")}
+        # dominant traversal kernel: the connection-ray launch (one per sample)
+        k_ms, k_rays, k_launches = c["ms_traverse_conn"], c["rays_traverse_conn"], c["launches_traverse_conn"]
+        k_name = "k_traverse_conn"
+        if c["ms_traverse_paths"] > k_ms:
+            k_ms, k_rays, k_launches, k_name = (c["ms_traverse_paths"], c["rays_traverse_paths"],
+                                                c["launches_traverse_paths"], "k_traverse_paths")
+        achieved = (k_rays * b_ray) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/sec (whole job), 1080p Cornell box BDPT",
+            "value": round(rays_total / dt / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Cornell box (scene preset 'empty', 16 tris / 5 boxes) {W}x{H}, BDPT diffuse-only, "
+                                   f"{args.steps} spp per GPU", "width": W, "height": H,
+                       "rays_per_pixel_sample": round(rays_local / (args.steps * W * H), 3),
+                       "parallelism": f"sample-split x{world}, one RCCL all-reduce of the accumulators"},
+            "roofline": {"bound": "hbm", "kernel": k_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "bytes_per_ray": round(b_ray, 1), "n_node": round(n_node, 3), "n_tri": round(n_tri, 3),
+                         "rays_per_launch": round(k_rays / max(k_launches, 1)),
+                         "avg_launch_ms": round(k_ms / max(k_launches, 1), 4)},
+            "stage_ms_total": stages,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_width, args.cpu_height, args.cpu_samples)
+        print(json.dumps(out), flush=True)
+
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
