@@ -207,9 +207,8 @@ class Renderer:
             torch.cuda.synchronize(self.device)
             self._check(self._L.cl2_copy_accumulators_from_device(self._h, C.c_void_p(t.data_ptr()), C.c_size_t(n)), "dev->acc")
         else:
-            t = torch.from_numpy(self.packed_accumulators())
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            self.load_packed_accumulators(t.numpy())
+            from .distributed import allreduce_packed_host
+            self.load_packed_accumulators(allreduce_packed_host(self.packed_accumulators(), group))
 
     # ---- counters / profiling ----
     def set_profiling(self, on=True):

@@ -1,0 +1,70 @@
+"""N > 1 path on CPU: world_size-2 gloo process group.  Each rank integrates its own samples
+(own seed buffer) -- here with the oracle standing in for the GPU -- and the packed accumulators
+are summed with the product's all-reduce helper; the result must equal the single-process sum and
+the radiance of the combined run (accumulators are pure sums)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, SPP = 24, 16, 3
+
+
+def _packed_from_oracle(o):
+    B = W * H
+    a = np.zeros((8, B), np.float32)
+    a[0:3] = o.summed_image.reshape(B, 3).T
+    a[3] = o.summed_sample_weights.reshape(B)
+    a[4:7] = o.unidirectional_image_buffer.reshape(B, 3).T
+    a[7] = o.summed_sample_counts.reshape(B)
+    return a.reshape(-1)
+
+
+def _render_rank(rank):
+    import clive2_amd as c2
+    from clive2_amd.renderer import make_seeds
+    from oracle import oracle as orc
+    scene = c2.create_scene_from_preset("empty", W, H)
+    o = orc.OracleRenderer(scene, seeds=make_seeds(W * H, rank=rank))
+    for _ in range(SPP):
+        o.run_sample()
+    return _packed_from_oracle(o)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), OMP_NUM_THREADS="2")
+    import torch.distributed as dist
+    from clive2_amd.distributed import allreduce_packed_host, rank_info
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert rank_info() == (rank, rank, world)
+    total = allreduce_packed_host(_render_rank(rank))
+    np.save(os.path.join(out_dir, f"total_{rank}.npy"), total)
+    dist.destroy_process_group()
+
+
+def test_two_rank_sum_reduce(tmp_path):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    t0, t1 = (np.load(tmp_path / f"total_{r}.npy") for r in (0, 1))
+    assert np.array_equal(t0, t1)                                  # all ranks hold the same sum
+    expect = _render_rank(0) + _render_rank(1)
+    assert np.array_equal(t0, expect)                              # two-term float sums are exact either way
+    from clive2_amd.distributed import radiance_from_packed
+    rad = radiance_from_packed(t0, H, W)
+    assert rad.shape == (H, W, 3) and np.isfinite(rad).all() and rad.mean() > 0
+    assert (t0.reshape(8, -1)[7] == 2 * SPP).all()                 # sample counts add up
+
+
+def test_sample_partition():
+    from clive2_amd.distributed import samples_for_rank
+    for total, world in ((1024, 8), (10, 4), (3, 8)):
+        parts = [samples_for_rank(total, r, world) for r in range(world)]
+        assert sum(parts) == total and max(parts) - min(parts) <= 1

@@ -1,0 +1,100 @@
+"""C-ABI shared library: builds for gfx950 without a GPU, loads, exports every symbol the header
+declares, and fails LOUDLY (no CPU fallback) when no GPU is present.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "clive2_amd.h")).read()
+    return sorted(set(re.findall(r"\b(cl2_[a-z_0-9]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def native_lib():
+    from clive2_amd import _native
+    _native.build()
+    return C.CDLL(_native.LIB_PATH)
+
+
+def test_every_declared_symbol_is_exported(native_lib):
+    from clive2_amd import _native
+    names = _declared()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(native_lib, n)]
+    assert missing == []
+    assert sorted(_native.EXPORTS) == names          # the binding knows exactly the header's surface
+    assert native_lib.cl2_abi_version() == 1
+
+
+def test_header_cites_the_reference_interface():
+    text = open(os.path.join(ROOT, "include", "clive2_amd.h")).read()
+    for cite in ("src/renderer.py:", "src/scene.py:", "src/struct_types.py:", "src/trace.metal:"):
+        assert cite in text
+
+
+def test_counters_struct_matches_header():
+    """ctypes mirror of cl2_counters has the header's field order and size."""
+    from clive2_amd._native import Counters
+    text = open(os.path.join(ROOT, "include", "clive2_amd.h")).read()
+    body = text[text.index("typedef struct {") + len("typedef struct {"):text.index("} cl2_counters;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        m = re.match(r"\s*(uint64_t|double)\s+(.*)", decl.strip(), flags=re.S)
+        if m:
+            fields += [n.strip() for n in m.group(2).split(",")]
+    assert fields == [n for n, _ in Counters._fields_]
+    assert C.sizeof(Counters) == 8 * len(fields)
+
+
+def _has_gpu():
+    return os.path.exists("/dev/kfd")
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
+def test_renderer_fails_loudly_without_gpu():
+    import clive2_amd as c2
+    from clive2_amd.renderer import Renderer, RendererError
+    scene = c2.create_scene_from_preset("empty", 16, 16)
+    with pytest.raises(RendererError) as e:
+        Renderer(scene)
+    assert "cl2_create failed" in str(e.value)
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    from clive2_amd import _native
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_native, "_lib", None)
+    with pytest.raises(_native.RendererError):
+        _native.lib()
+
+
+def test_product_path_does_not_touch_the_oracle():
+    """Nothing under clive2_amd/ (or bench.py outside cpu_baseline) may import oracle/."""
+    pkg = os.path.join(ROOT, "clive2_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "oracle/" not in src or f.endswith(".py") is False or "import" not in src.split("oracle/")[0][-40:], f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle import", bench)]
+    cb = bench.index("def cpu_baseline")
+    nxt = bench.index("def main")
+    assert uses and all(cb < u < nxt for u in uses)
+
+
+def test_make_seeds_contract():
+    from clive2_amd.renderer import make_seeds
+    a, b = make_seeds(100), make_seeds(100)
+    assert a.dtype == np.uint32 and a.shape == (100, 2) and np.array_equal(a, b) and (a != 0).all()
+    assert not np.array_equal(a, make_seeds(100, rank=1))
+    ref = np.random.RandomState(20240928).randint(0, 2 ** 32, size=(100, 2), dtype=np.uint32)
+    assert np.array_equal(a[ref != 0], ref[ref != 0])

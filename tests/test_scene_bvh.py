@@ -1,0 +1,127 @@
+"""Host plumbing: scene -> Box[] / Triangle[] / Material[] / Camera[]
+byte-exact against arrays captured from the reference's own host code
+(tests/golden/make_fixtures.py), plus structural invariants and the mesh readers."""
+import os
+import numpy as np
+import pytest
+
+import clive2_amd as c2
+from clive2_amd import struct_types as st
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _bytes(a):
+    return np.frombuffer(np.ascontiguousarray(a).tobytes(), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("w,h", [(256, 256), (1920, 1080), (64, 48)])
+def test_cornell_matches_reference(w, h):
+    s = c2.create_scene_from_preset("empty", w, h)
+    g = np.load(os.path.join(GOLD, f"cornell_{w}x{h}.npz"))
+    for k in ("boxes", "triangles", "materials", "camera", "light_triangles"):
+        assert np.array_equal(_bytes(getattr(s, k)), g[k]), k
+    assert np.array_equal(s.light_surface_areas, g["light_surface_areas"])
+    assert np.array_equal(s.light_triangle_indices, g["light_triangle_indices"])
+    assert np.array_equal(s.camera_triangle_indices, g["camera_triangle_indices"])
+    assert int(s.light_counts) == int(g["light_counts"][0]) == 2
+
+
+def test_cornell_facts_of_survey_8c():
+    s = c2.create_scene_from_preset("empty", 256, 256)
+    assert [(int(b["left"]), int(b["right"])) for b in s.boxes] == [(1, 0), (3, 0), (0, 4), (4, 12), (12, 16)]
+    assert list(s.triangles["material"]) == [7, 7, 3, 3, 4, 4, 4, 4, 1, 1, 2, 2, 6, 6, 4, 4]
+    cam = s.camera.reshape(-1)[0]
+    np.testing.assert_allclose(cam["focal_point"][:3], [0, 1.5, 5.649896], rtol=1e-6)
+    assert np.allclose(s.light_surface_areas, 12.5)
+    assert list(s.light_triangle_indices) == [12, 13] and list(s.camera_triangle_indices) == [0, 1]
+    c1080 = c2.create_scene_from_preset("empty", 1920, 1080).camera.reshape(-1)[0]
+    np.testing.assert_allclose([c1080["focal_point"][2], c1080["phys_width"], c1080["v_fov"]],
+                               [5.3775935, 1.7777778, 1.3535402], rtol=1e-6)
+
+
+@pytest.mark.parametrize("subdiv", [1, 2])
+def test_mesh_bvh_matches_reference(subdiv):
+    """fast_load (smooth normals) -> construct_BVH -> np_flatten_bvh on Cornell + icosphere."""
+    g = np.load(os.path.join(GOLD, f"cornell_icosphere{subdiv}_64x48.npz"))
+    s = c2.create_scene(64, 48, np.array([0, 1.5, 6]), np.array([0, 0, -1]),
+                        file_specs=[dict(mesh=(g["vertices"], g["faces"]), material=5)])
+    assert len(s.boxes) == int(g["n_boxes"]) and len(s.triangles) == int(g["n_triangles"])
+    assert np.array_equal(_bytes(s.boxes), g["boxes"])
+    assert np.array_equal(_bytes(s.triangles), g["triangles"])
+
+
+def test_bvh_invariants():
+    from clive2_amd.meshes import icosphere
+    v, f = icosphere(3, radius=2.0, center=(0, 1, 0))
+    s = c2.create_scene(32, 32, np.array([0, 1.5, 6]), np.array([0, 0, -1]), file_specs=[dict(mesh=(v, f), material=5)])
+    b, t = s.boxes, s.triangles
+    seen = np.zeros(len(t), int)
+    for i, box in enumerate(b):
+        if box["right"] == 0:          # inner: children later in BFS order and contained in the parent
+            for c in (box["left"], box["left"] + 1):
+                assert i < c < len(b)
+                assert (b[c]["min"][:3] >= box["min"][:3]).all() and (b[c]["max"][:3] <= box["max"][:3]).all()
+        else:
+            seen[box["left"]:box["right"]] += 1
+            tri = t[box["left"]:box["right"]]
+            pts = np.stack([tri["v0"], tri["v1"], tri["v2"]])[..., :3]
+            assert (pts >= box["min"][:3]).all() and (pts <= box["max"][:3]).all()
+            assert box["right"] - box["left"] <= 8
+    assert (seen == 1).all()           # every triangle in exactly one leaf (bvh.py:386-387)
+    assert s.validate()
+
+
+def test_scene_validate_rejects_bad_indices():
+    s = c2.create_scene_from_preset("empty", 16, 16)
+    s.boxes = s.boxes.copy()
+    s.boxes["left"][0] = 99
+    with pytest.raises(ValueError):
+        s.validate()
+
+
+def test_mesh_readers_round_trip(tmp_path):
+    from clive2_amd.meshes import icosphere
+    from clive2_amd import meshio, load
+    v, f = icosphere(1)
+    for binary in (True, False):
+        p = str(tmp_path / f"ico_{int(binary)}.ply")
+        meshio.write_ply(p, v, f, binary=binary)
+        rv, rf = meshio.read_ply(p)
+        assert rv.dtype == np.float32 and np.array_equal(rf, f)
+        np.testing.assert_allclose(rv, v.astype(np.float32), rtol=0, atol=0)
+    p = str(tmp_path / "ico.obj")
+    meshio.write_obj(p, v, f)
+    ov, of = meshio.read_obj(p)
+    assert np.array_equal(of, f) and np.array_equal(ov, v)
+    # file-based loaders feed the same fast_load as in-memory meshes (load.py:76-96)
+    a = load.fast_load_obj(p, offset=np.array([0, 1, 0]), material=5, scale=2.0)
+    b = load.fast_load(v * 2.0 + np.array([0, 1, 0]), f, material=5)
+    assert np.array_equal(a.triangles, b.triangles) and np.array_equal(a.smoothed_normals, b.smoothed_normals)
+
+
+def test_smooth_normals_point_outward_on_sphere():
+    from clive2_amd.meshes import icosphere
+    from clive2_amd.load import fast_load
+    v, f = icosphere(2)
+    soup = fast_load(v, f, material=5)
+    n = soup.smoothed_normals.reshape(-1, 3)
+    p = soup.triangles.reshape(-1, 3)
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0)
+    assert ((n * p).sum(axis=1) > 0.99).all()
+
+
+def test_tone_map_matches_reference():
+    g = np.load(os.path.join(GOLD, "tone_map.npz"))
+    assert np.array_equal(c2.tone_map(g["image"], exposure=4.0), g["out"])
+
+
+def test_presets_and_turntable():
+    assert set(c2.scene_presets) == {"empty", "teapots", "dragon", "medium-dragon", "big-dragon"}
+    with pytest.raises(ValueError):
+        c2.create_scene_from_preset("nope", 8, 8)
+    s = c2.create_scene_from_preset_with_params("empty", 32, 24, frame_idx=1, total_frames=4)
+    cam = s.camera.reshape(-1)[0]
+    np.testing.assert_allclose(cam["center"][:3], [7.5, 1.5, 0], atol=1e-6)
+    np.testing.assert_allclose(cam["direction"][:3], [-1, 0, 0], atol=1e-6)
+    assert len(s.triangles) == 16 and s.validate()
