@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-flags", type=int, default=0, help="performance experiments only (invalid renders)")
     ap.add_argument("--cpu-width", type=int, default=960)
     ap.add_argument("--cpu-height", type=int, default=540)
     ap.add_argument("--cpu-samples", type=int, default=1)
@@ -104,6 +105,8 @@ def main():
     r.reset_counters()
     r.reset_accumulators()
     r.set_profiling(True)
+    if args.debug_flags:
+        r.set_debug_flags(args.debug_flags)
 
     barrier()
     t0 = time.perf_counter()

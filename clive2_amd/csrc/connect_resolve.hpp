@@ -1,0 +1,305 @@
+// connect_resolve.hpp -- MIS weights and contributions of every (t,s) strategy pair of one pixel.
+//
+// Reference: the strategy loop of `connect_paths` (src/trace.metal:649-825) with its two BVH
+// queries replaced by the results of k_traverse_conn, the filter-weight epilogue (:827-868), the
+// light-image gather K8 (:937-964, here a float-atomic splat) and the unidirectional estimate of
+// `generate_paths` (:523-528).
+//
+// Formulation.  For a pair (t,s) the unified path is x_0..x_k, k = s+t-1, x_i = light[i] for i < s
+// and camera[t+s-i-1] otherwise (get_ray, :546-549).  The reference rebuilds all k+1 pdf ratios
+//     r_0 = l_0 / (c_0 G_01)      r_i = (l_i G_{i-1,i}) / (c_i G_{i,i+1})      r_k = (l_k G_{k,k-1}) / c_k
+// for every pair (:709-735).  All but the (at most) two ratios that touch the connection edge
+// depend on one subpath only, so they are evaluated ONCE per pixel with exactly the reference's
+// operations -- RL[i] for the light side, RC[m] for the camera side -- and each pair only computes
+// the junction geometry term, the two junction ratios and the two running products (:745-755).
+// Same float operations on the same operands in the same order => the aggregator is reproduced
+// exactly; per-pixel divisions drop from ~400 to ~250 and every path vertex is read from HBM once
+// (light subpath: registers, statically indexed because the s-loop is unrolled) or twice (camera).
+#pragma once
+#include "vecmath.hpp"
+#include "bsdf.hpp"
+
+namespace cl2 {
+
+struct LightVtx {
+    V3 o, n, col;
+    float c, l, tot, cosv;
+    int tri, meta;
+};
+
+// One strategy pair with s = S (compile time).  Returns true when a contribution was produced.
+template <int S>
+__device__ __forceinline__ void resolve_pair(
+        int t, int B, int pid, const LightVtx (&lv)[MAX_VERTS], const float (&GL)[MAX_VERTS], const float (&RL)[MAX_VERTS],
+        unsigned l_spec, unsigned c_spec, bool spec7,
+        // camera junction vertex t-1 and per-path camera tables (LDS)
+        V3 c_o_in, V3 c_n_in, float c_c, float c_l, float c_tot_in, float c_cos_in, int c_tri, int c_meta,
+        V3 prior_camera_color, const float* GCs, const float* RCs /* [m*BLOCK + tid] */,
+        unsigned long long mask, const float2* __restrict__ chit, const float4* __restrict__ tri_shade,
+        const MaterialDev* __restrict__ mats, const CameraRec& cam, V3 focal, V3 cam_dir,
+        V3& total, float& contrib_weight_sum, float4* __restrict__ light_image, int debug_flags) {
+    const int tid = threadIdx.x;
+    V3 c_o = c_o_in, c_n = c_n_in;
+    float c_tot = c_tot_in, c_cos = c_cos_in;
+    V3 dir_l_to_c = v3(0, 0, 0);
+    int light_pixel_idx = -1;
+    float Gj = 0.0f;
+
+    if (S == 0) {
+        if (!(c_meta & META_HIT_LIGHT)) return;                               // :665
+    } else {
+        if (!((mask >> conn_slot(t, S)) & 1ull)) return;                      // culled in k_connect_setup
+        const LightVtx& a = lv[S - 1];
+        const float2 h = chit[(size_t)conn_slot(t, S) * B + pid];
+        const int best_i = __float_as_int(h.x);
+        if (best_i == -1) return;                                             // :193 / :593
+        if (t == 1) {
+            // world_ray_to_camera_ray, :595-616
+            if (__float_as_int(tri_shade[4 * best_i + 2].w) == 0) return;     // !is_camera
+            const V3 tdir = normalize(focal - a.o);
+            const V3 camera_point = a.o + h.y * tdir;
+            const float x = dot(camera_point - cam3(cam.center), cam3(cam.dx));
+            const float y = dot(camera_point - cam3(cam.center), cam3(cam.dy));
+            const int pixel_x = (int)__builtin_roundf((x / cam.phys_width + 0.5f) * cam.pixel_width);
+            const int pixel_y = (int)__builtin_roundf((y / cam.phys_height + 0.5f) * cam.pixel_height);
+            light_pixel_idx = pixel_y * cam.pixel_width + pixel_x;
+            if (light_pixel_idx == -1) return;                                // :671
+            c_o = camera_point;
+            const V3 cdir = normalize(focal - camera_point);
+            c_n = cam_dir;
+            c_cos = __builtin_fabsf(dot(cdir, cam_dir));
+            c_tot = 1.0f;
+        } else {
+            if (best_i == a.tri) return;                                      // visibility_test, :194-196
+            if (best_i != c_tri) return;
+        }
+        dir_l_to_c = normalize(c_o - a.o);
+        Gj = geom_term(a.cosv, c_cos, a.o, c_o);
+    }
+
+    // ---- p_s and the two running products (:737-757) ----
+    const float p_s = c_tot * ((S == 0) ? 1.0f : lv[S > 0 ? S - 1 : 0].tot);
+    // backward (light side): p[i] = p[i+1] / r_i for i = S-1 .. 0
+    float pb[MAX_VERTS > 0 ? MAX_VERTS : 1];
+    if (S > 0) {
+        const LightVtx& a = lv[S - 1];
+        const float r_junc = (S == 1) ? a.l / (a.c * Gj) : (a.l * GL[S - 2]) / (a.c * Gj);
+        float v = p_s / r_junc;
+        pb[S - 1] = v;
+#pragma unroll
+        for (int i = S - 2; i >= 0; i--) { v = v / RL[i]; pb[i] = v; }
+    }
+    // specular zeroing (:759-764): p[i] is zeroed when x_i or x_{i-1} is specular
+    auto spec_at = [&](int i) -> bool {        // unified index -> material type > 0
+        if (i < S) return (l_spec >> i) & 1u;
+        const int m = t + S - i - 1;
+        if (t == 1 && S > 0) return spec7;       // projected camera vertex carries material 7 (:611)
+        return (c_spec >> m) & 1u;
+    };
+    float sum = 0.0f;
+    bool prev_spec = false;
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+        const bool sp = (l_spec >> i) & 1u;
+        sum += (sp || prev_spec) ? 0.0f : pb[i];
+        prev_spec = sp;
+    }
+    // i = S: p[S] = p_s
+    bool sp_s = spec_at(S);
+    const float p_at_s = (sp_s || prev_spec) ? 0.0f : p_s;
+    sum += p_at_s;
+    prev_spec = sp_s;
+    // forward (camera side): p[i+1] = r_i * p[i], i = S .. S+t-2 useful (p[S+t] is overwritten by 0, :766)
+    {
+        float v = p_s;
+        for (int i = S; i < S + t - 1; i++) {
+            float r;
+            if (i == S) {
+                if (S == 0) r = c_l / (c_c * GCs[(t - 2) * BLOCK + tid]);            // i == 0 form, x_1 = camera[t-2]
+                else r = (c_l * Gj) / (c_c * GCs[(t - 2) * BLOCK + tid]);           // interior form at the junction
+            } else {
+                r = RCs[(t + S - i - 1) * BLOCK + tid];
+            }
+            v = r * v;
+            const bool sp = spec_at(i + 1);
+            sum += (sp || prev_spec) ? 0.0f : v;
+            prev_spec = sp;
+        }
+    }
+    sum += 0.0f;                                                              // p[S+t] = 0
+    if (!(p_at_s > 0.0f && sum > 0.0f)) return;                               // :773-776
+    const float w = p_at_s / sum;
+
+    if (S == 0) {                                                             // :783-786
+        const V3 emission = v3(mats[c_meta & 0xFF].emission_alpha);
+        const V3 color = prior_camera_color * emission;
+        total = total + ((w * 1.0f) * color) / p_s;
+        contrib_weight_sum += w;
+    } else if (t == 1) {                                                      // :787-793, :817-823, K8 :952-961
+        const LightVtx& a = lv[S - 1];
+        const V3 prior_color = lv[(S - 2) > 0 ? (S - 2) : 0].col;
+        float new_light_f = 1.0f;
+        if (S > 1) new_light_f = __builtin_fabsf(dot(dir_l_to_c, a.n)) / PI_F;
+        const V3 mcol = v3(mats[a.meta & 0xFF].color_type);
+        const float shade = new_light_f * Gj / p_s;
+        if (light_pixel_idx >= 0 && light_pixel_idx < B && !(debug_flags & 1)) {
+            const V3 c = ((w * shade) * prior_color) * mcol;
+            float* dst = reinterpret_cast<float*>(&light_image[light_pixel_idx]);
+            atomicAdd(dst + 0, c.x);
+            atomicAdd(dst + 1, c.y);
+            atomicAdd(dst + 2, c.z);
+            atomicAdd(dst + 3, w);
+        }
+    } else {                                                                  // :794-816
+        const LightVtx& a = lv[S - 1];
+        const MaterialDev cmat = mats[c_meta & 0xFF];
+        const float new_camera_f = __builtin_fabsf(dot(-dir_l_to_c, c_n)) / PI_F;
+        const V3 camera_color = (prior_camera_color * new_camera_f) * v3(cmat.color_type);
+        V3 light_color;
+        if (S == 1) light_color = v3(mats[a.meta & 0xFF].emission_alpha);
+        else {
+            const V3 prior_light_color = lv[S >= 2 ? S - 2 : 0].col;
+            const float new_light_f = __builtin_fabsf(dot(dir_l_to_c, a.n)) / PI_F;
+            light_color = (prior_light_color * new_light_f) * v3(mats[a.meta & 0xFF].color_type);
+        }
+        const V3 color = camera_color * light_color;
+        total = total + ((w * Gj) * color) / p_s;
+        contrib_weight_sum += w;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_connect_resolve(
+        int B, PathBufs lp, PathBufs cp, const MaterialDev* __restrict__ mats,
+        const float4* __restrict__ tri_shade, CameraRec cam, const unsigned long long* __restrict__ cmask,
+        const float2* __restrict__ chit, float* __restrict__ agg, float4* __restrict__ light_image,
+        float4* __restrict__ uni_out, Stats* stats, int debug_flags) {
+    __shared__ float GCs[(MAX_VERTS - 1) * BLOCK];     // GC[v] = G(camera[v], camera[v+1])
+    __shared__ float RCs[(MAX_VERTS - 1) * BLOCK];     // RC[m]: ratio of camera vertex m with both neighbours on the camera side
+    const int tid = threadIdx.x;
+    const int pid = blockIdx.x * BLOCK + tid;
+    if (pid >= B) return;                              // no block-wide barrier below: LDS rows are private per thread
+    const int Lc = cp.len[pid], Ll = lp.len[pid];
+    const unsigned long long mask = cmask[pid];
+    const V3 focal = cam3(cam.focal_point), cam_dir = cam3(cam.direction);
+    const bool spec7 = __float_as_int(mats[7].color_type.w) > 0;
+
+    // ---- light subpath -> registers; adjacent geometry terms and interior ratios ----
+    LightVtx lv[MAX_VERTS];
+    float GL[MAX_VERTS], RL[MAX_VERTS];
+    unsigned l_spec = 0;
+#pragma unroll
+    for (int v = 0; v < MAX_VERTS; v++) {
+        lv[v] = LightVtx{v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), 0.0f, 0.0f, 0.0f, 0.0f, -1, 0};
+        GL[v] = 0.0f; RL[v] = 0.0f;
+        if (v < Ll) {
+            const size_t k = (size_t)v * B + pid;
+            const float4 a = lp.P0[k], b = lp.P1[k], c = lp.P2[k], d = lp.P3[k];
+            lv[v].o = v3(a); lv[v].n = v3(c); lv[v].col = v3(d);
+            lv[v].c = a.w; lv[v].l = b.w; lv[v].tot = d.w;
+            lv[v].cosv = __builtin_fabsf(dot(v3(b), v3(c)));
+            lv[v].tri = lp.tri[k];
+            lv[v].meta = __float_as_int(c.w);
+            if (__float_as_int(mats[lv[v].meta & 0xFF].color_type.w) > 0) l_spec |= 1u << v;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v + 1 < MAX_VERTS; v++)
+        if (v + 1 < Ll) GL[v] = geom_term(lv[v].cosv, lv[v + 1].cosv, lv[v].o, lv[v + 1].o);
+#pragma unroll
+    for (int i = 0; i + 1 < MAX_VERTS; i++) {
+        if (i + 1 < Ll) {
+            if (i == 0) RL[0] = lv[0].l / (lv[0].c * GL[0]);
+            else RL[i] = (lv[i].l * GL[i - 1]) / (lv[i].c * GL[i]);
+        }
+    }
+
+    // ---- camera subpath: per-path tables to LDS ----
+    unsigned c_spec = 0;
+    {
+        V3 prev_o = v3(0, 0, 0);
+        float prev_cos = 0.0f, prev_l = 0.0f, prev_c = 0.0f, prev_G = 0.0f;
+        for (int v = 0; v < Lc; v++) {
+            const size_t k = (size_t)v * B + pid;
+            const float4 a = cp.P0[k], b = cp.P1[k], c = cp.P2[k];
+            const float cosv = __builtin_fabsf(dot(v3(b), v3(c)));
+            if (__float_as_int(mats[__float_as_int(c.w) & 0xFF].color_type.w) > 0) c_spec |= 1u << v;
+            if (v > 0) {
+                const float G = geom_term(prev_cos, cosv, prev_o, v3(a));          // GC[v-1]
+                GCs[(v - 1) * BLOCK + tid] = G;
+                // ratio of camera vertex m = v-1 once its far neighbour (v) is known
+                const int m = v - 1;
+                RCs[m * BLOCK + tid] = (m == 0) ? (prev_l * G) / prev_c : (prev_l * G) / (prev_c * prev_G);
+                prev_G = G;
+            }
+            prev_o = v3(a); prev_cos = cosv; prev_l = b.w; prev_c = a.w;
+        }
+    }
+
+    V3 total = v3(0, 0, 0);
+    float contrib_weight_sum = 0.0f;
+
+    for (int t = 1; t < Lc + 1; t++) {
+        const size_t ck = (size_t)(t - 1) * B + pid;
+        const float4 cP0 = cp.P0[ck], cP1 = cp.P1[ck], cP2 = cp.P2[ck], cP3 = cp.P3[ck];
+        const int c_meta = __float_as_int(cP2.w);
+        const int c_tri = cp.tri[ck];
+        const V3 c_o = v3(cP0), c_n = v3(cP2);
+        const float c_cos = __builtin_fabsf(dot(v3(cP1), c_n));
+        V3 prior_camera_color = v3(0, 0, 0);
+        if (t >= 2) prior_camera_color = v3(cp.P3[ck - B]);
+#define CL2_PAIR(S)                                                                                             \
+        if ((S) <= Ll && t + (S) >= 2)                                                                          \
+            resolve_pair<S>(t, B, pid, lv, GL, RL, l_spec, c_spec, spec7, c_o, c_n, cP0.w, cP1.w, cP3.w, c_cos, \
+                            c_tri, c_meta, prior_camera_color, GCs, RCs, mask, chit, tri_shade, mats, cam,     \
+                            focal, cam_dir, total, contrib_weight_sum, light_image, debug_flags)
+        CL2_PAIR(0); CL2_PAIR(1); CL2_PAIR(2); CL2_PAIR(3); CL2_PAIR(4); CL2_PAIR(5); CL2_PAIR(6);
+#undef CL2_PAIR
+    }
+
+    // ---- reconstruction-filter weights, trace.metal:827-862.  A zero-length camera path is the
+    // reference's zero-filled Path: pixel 0, film point (0,0,0). ----
+    const int pixel_idx = (Lc > 0) ? pid : 0;
+    V3 film = v3(0, 0, 0);
+    if (Lc > 0) film = v3(cp.P0[pid]);
+    const float ppw = cam.phys_width / cam.pixel_width, pph = cam.phys_height / cam.pixel_height;
+    const float sigma = 0.5f * __builtin_sqrtf(ppw * ppw + pph * pph);
+    float wts[9];
+    float weight_sum = 0.0f;
+#pragma unroll
+    for (int i = -1; i < 2; i++) {
+#pragma unroll
+        for (int j = -1; j < 2; j++) {
+            wts[(i + 1) * 3 + (j + 1)] = 0.0f;
+            const int nx = (pixel_idx % cam.pixel_width) + i, ny = (pixel_idx / cam.pixel_width) + j;
+            if (nx < 0 || nx >= cam.pixel_width || ny < 0 || ny >= cam.pixel_height) continue;
+            // pixel_center, trace.metal:551-562 (no +0.5)
+            const float xn = (nx - 0.5f * cam.pixel_width) / (float)cam.pixel_width;
+            const float yn = (ny - 0.5f * cam.pixel_height) / (float)cam.pixel_height;
+            const V3 pc = (cam3(cam.center) + (xn * cam.phys_width) * cam3(cam.dx)) + (yn * cam.phys_height) * cam3(cam.dy);
+            const float dist = length3(pc - film);
+            const float wgt = det_expf(-dist * dist / (2.0f * sigma * sigma));
+            wts[(i + 1) * 3 + (j + 1)] = wgt;
+            weight_sum += wgt;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 9; r++) agg[(size_t)r * B + pid] = (weight_sum != 0.0f) ? wts[r] / weight_sum : wts[r];
+    agg[(size_t)9 * B + pid] = total.x;
+    agg[(size_t)10 * B + pid] = total.y;
+    agg[(size_t)11 * B + pid] = total.z;
+    agg[(size_t)12 * B + pid] = contrib_weight_sum;
+
+    // ---- unidirectional estimate of generate_paths (camera pass), trace.metal:523-528 ----
+    float4 uni = make_float4(0, 0, 0, 0);
+    for (int v = 1; v < Lc; v++) {
+        const size_t kk = (size_t)v * B + pid;
+        if (__float_as_int(cp.P2[kk].w) & META_HIT_LIGHT) {
+            const V3 c = v3(cp.P3[kk - B]) / cp.P3[kk].w;
+            uni = make_float4(c.x, c.y, c.z, 1.0f);
+            break;
+        }
+    }
+    uni_out[pid] = uni;
+}
+
+}  // namespace cl2

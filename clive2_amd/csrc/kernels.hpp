@@ -413,241 +413,9 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_conn(
 // Aggregator SoA rows: 0..8 weights[i][j] (row i*3+j), 9..11 total_contribution, 12 contrib_weight_sum.
 constexpr int AGG_ROWS = 13;
 
-// Per-pixel strategy loop of connect_paths (trace.metal:649-868) with the BVH queries replaced by
-// the results of traverse_conn.  Accumulation order is the reference's, so the aggregator is
-// reproducible; only the t=1 splats (float atomics) are order-dependent.
-__global__ __launch_bounds__(BLOCK) void k_connect_resolve(
-        int B, PathBufs lp, PathBufs cp, const MaterialDev* __restrict__ mats,
-        const float4* __restrict__ tri_shade, CameraRec cam, const unsigned long long* __restrict__ cmask,
-        const float2* __restrict__ chit, float* __restrict__ agg, float4* __restrict__ light_image,
-        float4* __restrict__ uni_out, Stats* stats) {
-    const int pid = blockIdx.x * BLOCK + threadIdx.x;
-    if (pid >= B) return;
-    const int Lc = cp.len[pid], Ll = lp.len[pid];
-    const unsigned long long mask = cmask[pid];
-    const V3 focal = cam3(cam.focal_point), cam_dir = cam3(cam.direction);
-
-    // per-vertex scalars of both subpaths
-    float l_c[MAX_VERTS], l_l[MAX_VERTS], l_cos[MAX_VERTS], c_c[MAX_VERTS], c_l[MAX_VERTS], c_cos[MAX_VERTS];
-    float GL[MAX_VERTS], GC[MAX_VERTS];     // GL[v] = G(light[v], light[v+1]), GC likewise
-    unsigned l_spec = 0, c_spec = 0;        // bit v: material type > 0
-    {
-        V3 prev_o = v3(0, 0, 0);
-#pragma unroll
-        for (int v = 0; v < MAX_VERTS; v++) {
-            l_c[v] = l_l[v] = l_cos[v] = GL[v] = 0.0f;
-            if (v < Ll) {
-                const size_t k = (size_t)v * B + pid;
-                const float4 a = lp.P0[k], b = lp.P1[k], c = lp.P2[k];
-                l_c[v] = a.w; l_l[v] = b.w;
-                l_cos[v] = __builtin_fabsf(dot(v3(b), v3(c)));
-                if (__float_as_int(mats[__float_as_int(c.w) & 0xFF].color_type.w) > 0) l_spec |= 1u << v;
-                if (v > 0) GL[v - 1] = geom_term(l_cos[v - 1], l_cos[v], prev_o, v3(a));
-                prev_o = v3(a);
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < MAX_VERTS; v++) {
-            c_c[v] = c_l[v] = c_cos[v] = GC[v] = 0.0f;
-            if (v < Lc) {
-                const size_t k = (size_t)v * B + pid;
-                const float4 a = cp.P0[k], b = cp.P1[k], c = cp.P2[k];
-                c_c[v] = a.w; c_l[v] = b.w;
-                c_cos[v] = __builtin_fabsf(dot(v3(b), v3(c)));
-                if (__float_as_int(mats[__float_as_int(c.w) & 0xFF].color_type.w) > 0) c_spec |= 1u << v;
-                if (v > 0) GC[v - 1] = geom_term(c_cos[v - 1], c_cos[v], prev_o, v3(a));
-                prev_o = v3(a);
-            }
-        }
-    }
-
-    V3 total = v3(0, 0, 0);
-    float contrib_weight_sum = 0.0f;
-
-    for (int t = 1; t < Lc + 1; t++) {
-        // camera vertex t-1 (the stored one; for t == 1 the projected vertex replaces it per s)
-        const size_t ck = (size_t)(t - 1) * B + pid;
-        const float4 cP0 = cp.P0[ck], cP2 = cp.P2[ck], cP3 = cp.P3[ck];
-        const int c_meta = __float_as_int(cP2.w);
-        const int c_tri = cp.tri[ck];
-        V3 prior_camera_color = v3(0, 0, 0);
-        if (t >= 2) prior_camera_color = v3(cp.P3[ck - B]);
-
-        for (int s = 0; s < Ll + 1; s++) {
-            if (t + s < 2) continue;
-            // junction data
-            V3 l_o = v3(0, 0, 0), l_n = v3(0, 0, 0), dir_l_to_c = v3(0, 0, 0);
-            float l_tot = 1.0f, l_cos_s = 0.0f;
-            int l_meta = 0;
-            V3 c_o = v3(cP0), c_n = v3(cP2);
-            float c_tot = cP3.w, c_cos_t = c_cos[t - 1];
-            int cm_meta = c_meta;
-            int light_pixel_idx = -1;
-
-            if (s == 0) {
-                if (!(c_meta & META_HIT_LIGHT)) continue;                       // :665
-            } else {
-                const size_t lk = (size_t)(s - 1) * B + pid;
-                if (!((mask >> conn_slot(t, s)) & 1ull)) continue;              // culled in setup
-                const float4 lP0 = lp.P0[lk], lP2 = lp.P2[lk];
-                l_o = v3(lP0); l_n = v3(lP2); l_meta = __float_as_int(lP2.w);
-                l_tot = lp.P3[lk].w; l_cos_s = l_cos[s - 1];
-                const float2 h = chit[(size_t)conn_slot(t, s) * B + pid];
-                const int best_i = __float_as_int(h.x);
-                const int l_tri = lp.tri[lk];
-                if (t == 1) {
-                    // world_ray_to_camera_ray, trace.metal:593-616
-                    if (best_i == -1) continue;
-                    if (__float_as_int(tri_shade[4 * best_i + 2].w) == 0) continue;   // !is_camera
-                    const V3 tdir = normalize(focal - l_o);
-                    const V3 camera_point = l_o + h.y * tdir;
-                    const float x = dot(camera_point - cam3(cam.center), cam3(cam.dx));
-                    const float y = dot(camera_point - cam3(cam.center), cam3(cam.dy));
-                    const int pixel_x = (int)__builtin_roundf((x / cam.phys_width + 0.5f) * cam.pixel_width);
-                    const int pixel_y = (int)__builtin_roundf((y / cam.phys_height + 0.5f) * cam.pixel_height);
-                    light_pixel_idx = pixel_y * cam.pixel_width + pixel_x;
-                    if (light_pixel_idx == -1) continue;                        // :671
-                    c_o = camera_point;
-                    const V3 cdir = normalize(focal - camera_point);
-                    c_n = cam_dir;
-                    c_cos_t = __builtin_fabsf(dot(cdir, cam_dir));
-                    c_tot = 1.0f;
-                    cm_meta = 7 | META_HIT_CAMERA;
-                    dir_l_to_c = normalize(c_o - l_o);
-                } else {
-                    // visibility_test, trace.metal:193-196
-                    if (best_i == -1) continue;
-                    if (best_i == l_tri) continue;
-                    if (best_i != c_tri) continue;
-                    dir_l_to_c = normalize(c_o - l_o);
-                }
-            }
-
-            const int k = s + t - 1;                       // last unified vertex index
-            float Gj = 0.0f;
-            if (s > 0) Gj = geom_term(l_cos_s, c_cos_t, l_o, c_o);
-            // unified accessors (get_ray, trace.metal:546-549)
-            auto xl = [&](int i) { return i < s ? l_l[i] : c_l[t + s - i - 1]; };
-            auto xc = [&](int i) { return i < s ? l_c[i] : c_c[t + s - i - 1]; };
-            auto Gadj = [&](int i) {                       // G(x_i, x_{i+1})
-                return (i + 1 < s) ? GL[i] : ((i + 1 == s) ? Gj : GC[t + s - i - 2]);
-            };
-            float p_ratios[14], p_values[15];
-#pragma unroll
-            for (int i = 0; i < 14; i++) p_ratios[i] = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 15; i++) p_values[i] = 0.0f;
-            for (int i = 0; i < s + t; i++) {              // :709-735
-                float num, denom;
-                if (i == 0) { num = xl(0); denom = xc(0) * Gadj(0); }
-                else if (i == k) { num = xl(k) * Gadj(k - 1); denom = xc(k); }
-                else { num = xl(i) * Gadj(i - 1); denom = xc(i) * Gadj(i); }
-                p_ratios[i] = num / denom;
-            }
-            const float p_s = c_tot * ((s == 0) ? 1.0f : l_tot);                 // :737-743
-            float p_i = p_s;
-            for (int i = s; i < s + t + 1; i++) { p_values[i + 1] = p_ratios[i] * p_i; p_i = p_values[i + 1]; }
-            p_i = p_s;
-            for (int i = s - 1; i >= 0; i--) { p_values[i] = p_i / p_ratios[i]; p_i = p_values[i]; }
-            p_values[s] = p_s;
-            for (int i = 0; i < s + t; i++) {              // :759-764
-                bool spec;
-                if (i < s) spec = (l_spec >> i) & 1u;
-                else {
-                    const int m = t + s - i - 1;
-                    spec = (t == 1 && s > 0) ? false /* projected vertex: material 7 */ : ((c_spec >> m) & 1u);
-                }
-                if (spec) { p_values[i] = 0.0f; p_values[i + 1] = 0.0f; }
-            }
-            p_values[s + t] = 0.0f;
-            float sum = 0.0f;
-            for (int i = 0; i < s + t + 1; i++) sum += p_values[i];
-            if (!(p_values[s] > 0.0f && sum > 0.0f)) continue;
-            const float w = p_values[s] / sum;
-
-            if (s == 0) {                                   // :783-786
-                const V3 emission = v3(mats[cm_meta & 0xFF].emission_alpha);
-                const V3 color = prior_camera_color * emission;
-                total = total + ((w * 1.0f) * color) / p_s;
-                contrib_weight_sum += w;
-            } else if (t == 1) {                            // :787-793, :817-823, and K8 :952-961
-                const int prior = (s - 2) > 0 ? (s - 2) : 0;
-                const V3 prior_color = v3(lp.P3[(size_t)prior * B + pid]);
-                float new_light_f = 1.0f;
-                if (s > 1) new_light_f = __builtin_fabsf(dot(dir_l_to_c, l_n)) / PI_F;
-                const V3 mcol = v3(mats[l_meta & 0xFF].color_type);
-                const float shade = new_light_f * Gj / p_s;
-                if (light_pixel_idx >= 0 && light_pixel_idx < B) {
-                    const V3 c = ((w * shade) * prior_color) * mcol;
-                    float* dst = reinterpret_cast<float*>(&light_image[light_pixel_idx]);
-                    atomicAdd(dst + 0, c.x);
-                    atomicAdd(dst + 1, c.y);
-                    atomicAdd(dst + 2, c.z);
-                    atomicAdd(dst + 3, w);
-                }
-            } else {                                        // :794-816
-                const MaterialDev cmat = mats[cm_meta & 0xFF];
-                const float new_camera_f = __builtin_fabsf(dot(-dir_l_to_c, c_n)) / PI_F;
-                const V3 camera_color = (prior_camera_color * new_camera_f) * v3(cmat.color_type);
-                V3 light_color;
-                if (s == 1) light_color = v3(mats[l_meta & 0xFF].emission_alpha);
-                else {
-                    const V3 prior_light_color = v3(lp.P3[(size_t)(s - 2) * B + pid]);
-                    const float new_light_f = __builtin_fabsf(dot(dir_l_to_c, l_n)) / PI_F;
-                    light_color = (prior_light_color * new_light_f) * v3(mats[l_meta & 0xFF].color_type);
-                }
-                const V3 color = camera_color * light_color;
-                total = total + ((w * Gj) * color) / p_s;
-                contrib_weight_sum += w;
-            }
-        }
-    }
-
-    // reconstruction-filter weights, trace.metal:827-862.  A zero-length camera path is the
-    // reference's zero-filled Path: pixel 0, film point (0,0,0).
-    const int pixel_idx = (Lc > 0) ? pid : 0;
-    V3 film = v3(0, 0, 0);
-    if (Lc > 0) film = v3(cp.P0[pid]);
-    const float ppw = cam.phys_width / cam.pixel_width, pph = cam.phys_height / cam.pixel_height;
-    const float sigma = 0.5f * __builtin_sqrtf(ppw * ppw + pph * pph);
-    float wts[9];
-    float weight_sum = 0.0f;
-#pragma unroll
-    for (int i = -1; i < 2; i++) {
-#pragma unroll
-        for (int j = -1; j < 2; j++) {
-            wts[(i + 1) * 3 + (j + 1)] = 0.0f;
-            const int nx = (pixel_idx % cam.pixel_width) + i, ny = (pixel_idx / cam.pixel_width) + j;
-            if (nx < 0 || nx >= cam.pixel_width || ny < 0 || ny >= cam.pixel_height) continue;
-            // pixel_center, trace.metal:551-562 (no +0.5)
-            const float xn = (nx - 0.5f * cam.pixel_width) / (float)cam.pixel_width;
-            const float yn = (ny - 0.5f * cam.pixel_height) / (float)cam.pixel_height;
-            const V3 pc = (cam3(cam.center) + (xn * cam.phys_width) * cam3(cam.dx)) + (yn * cam.phys_height) * cam3(cam.dy);
-            const float dist = length3(pc - film);
-            const float wgt = det_expf(-dist * dist / (2.0f * sigma * sigma));
-            wts[(i + 1) * 3 + (j + 1)] = wgt;
-            weight_sum += wgt;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 9; r++) agg[(size_t)r * B + pid] = (weight_sum != 0.0f) ? wts[r] / weight_sum : wts[r];
-    agg[(size_t)9 * B + pid] = total.x;
-    agg[(size_t)10 * B + pid] = total.y;
-    agg[(size_t)11 * B + pid] = total.z;
-    agg[(size_t)12 * B + pid] = contrib_weight_sum;
-
-    // unidirectional estimate of generate_paths (camera pass), trace.metal:523-528
-    float4 uni = make_float4(0, 0, 0, 0);
-    for (int v = 1; v < Lc; v++) {
-        const size_t kk = (size_t)v * B + pid;
-        if (__float_as_int(cp.P2[kk].w) & META_HIT_LIGHT) {
-            const V3 c = v3(cp.P3[kk - B]) / cp.P3[kk].w;
-            uni = make_float4(c.x, c.y, c.z, 1.0f);
-            break;
-        }
-    }
-    uni_out[pid] = uni;
-}
+}  // namespace cl2
+#include "connect_resolve.hpp"
+namespace cl2 {
 
 // ---------------------------------------------------------------- K6: adaptive_finalize_samples
 // trace.metal:981-1018 with identity sample bins (renderer.py:92-94).

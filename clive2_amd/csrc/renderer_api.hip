@@ -43,6 +43,7 @@ struct cl2_renderer {
     hipStream_t stream = nullptr;
     std::string err;
     bool scene_ok = false, profiling = false, counting = false;
+    int debug_flags = 0;
 
     // scene
     BvhView bvh{};
@@ -214,7 +215,7 @@ int launch_join(cl2_renderer* r) {
     {
         Timed t(r, ST_CONNECT_RESOLVE);
         hipLaunchKernelGGL(k_connect_resolve, dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, B, r->pb[CL2_LIGHT], r->pb[CL2_CAMERA],
-                           r->d_mats, r->d_tri_shade, r->cam, r->d_cmask, r->d_chit, r->d_agg, r->d_light_image, r->d_uni, r->d_stats);
+                           r->d_mats, r->d_tri_shade, r->cam, r->d_cmask, r->d_chit, r->d_agg, r->d_light_image, r->d_uni, r->d_stats, r->debug_flags);
     }
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;
@@ -539,6 +540,7 @@ int cl2_copy_accumulators_to_device(cl2_renderer* r, void* dst, size_t n) { retu
 int cl2_copy_accumulators_from_device(cl2_renderer* r, const void* src, size_t n) { return acc_copy(r, r ? r->d_acc : nullptr, src, n, hipMemcpyDeviceToDevice); }
 
 int cl2_set_profiling(cl2_renderer* r, int on) { if (!r) return CL2_E_INVALID; r->profiling = on != 0; return CL2_OK; }
+int cl2_set_debug_flags(cl2_renderer* r, int flags) { if (!r) return CL2_E_INVALID; r->debug_flags = flags; return CL2_OK; }
 int cl2_set_counting(cl2_renderer* r, int on) { if (!r) return CL2_E_INVALID; r->counting = on != 0; return CL2_OK; }
 
 int cl2_read_counters(cl2_renderer* r, cl2_counters* out) {

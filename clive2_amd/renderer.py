@@ -217,6 +217,9 @@ class Renderer:
     def set_counting(self, on=True):
         self._check(self._L.cl2_set_counting(self._h, int(bool(on))), "set_counting")
 
+    def set_debug_flags(self, flags):
+        self._check(self._L.cl2_set_debug_flags(self._h, int(flags)), "set_debug_flags")
+
     def counters(self):
         c = Counters()
         self._check(self._L.cl2_read_counters(self._h, C.byref(c)), "read_counters")

@@ -110,6 +110,9 @@ int cl2_copy_accumulators_from_device(cl2_renderer* r, const void* device_src, s
 int cl2_set_profiling(cl2_renderer* r, int on);     /* HIP-event timers per stage */
 int cl2_set_counting(cl2_renderer* r, int on);      /* node / triangle test tallies in the traversal kernels */
 int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
+/* performance-experiment switches; results are NOT valid renders when any bit is set.
+ * bit 0: skip the t=1 light-image splat atomics. */
+int cl2_set_debug_flags(cl2_renderer* r, int flags);
 int cl2_reset_counters(cl2_renderer* r);
 
 /* -- debug exports in the reference's AoS layouts (stage-level parity) -- */
