@@ -57,23 +57,38 @@ __device__ __forceinline__ void stage_bvh(BvhLds& s, const BvhView& b) {
 
 struct Hit { int tri; float t, u, v; };
 
-// Closest hit along (o, d) with inv = 1/d.  COUNT adds node/triangle test tallies.
-template <bool COUNT>
-__device__ __forceinline__ Hit closest_hit(const BvhLds& s, const BvhView& b, V3 o, V3 d, V3 inv,
-                                          unsigned& n_box, unsigned& n_tri) {
+// Closest hit along (o, d) with inv = 1/d.
+//   COUNT    adds node/triangle test tallies.
+//   ALL_LDS  the whole tree and all triangles are staged in LDS (small scenes): plain ds_read, no
+//            per-access LDS/global pointer select.
+//   FAST_MINMAX  the slab test uses v_min/v_max instead of the compare+select form of the MSL
+//            min/max.  The two differ only when an operand is NaN (0 * inf, i.e. a direction
+//            component is exactly 0 and the origin lies on a slab plane) or in the sign of a zero,
+//            and a zero's sign never reaches a decision (the slab values only feed comparisons);
+//            the caller selects FAST_MINMAX only for waves whose rays all have finite 1/d.
+template <bool COUNT, bool ALL_LDS, bool FAST_MINMAX>
+__device__ __forceinline__ Hit closest_hit_impl(const BvhLds& s, const BvhView& b, V3 o, V3 d, V3 inv,
+                                               unsigned& n_box, unsigned& n_tri) {
     Hit best{-1, __builtin_inff(), 0.0f, 0.0f};
     int node = 0;
     while (node >= 0) {
         float4 lo, hi;
         int next;
-        if (node < b.n_lds_nodes) { lo = s.nodes[2 * node]; hi = s.nodes[2 * node + 1]; next = s.skip[node]; }
+        if (ALL_LDS || node < b.n_lds_nodes) { lo = s.nodes[2 * node]; hi = s.nodes[2 * node + 1]; next = s.skip[node]; }
         else { lo = b.nodes[2 * node]; hi = b.nodes[2 * node + 1]; next = b.skip[node]; }
         if (COUNT) n_box++;
         // ray_box_intersect, trace.metal:106-115 (called with t = INFINITY, :153-155)
         float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
         float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
-        float tmin = max_msl(max_msl(min_msl(t0x, t1x), min_msl(t0y, t1y)), max_msl(min_msl(t0z, t1z), 0.0f));
-        float tmax = min_msl(min_msl(max_msl(t0x, t1x), max_msl(t0y, t1y)), min_msl(max_msl(t0z, t1z), __builtin_inff()));
+        float tmin, tmax;
+        if (FAST_MINMAX) {
+            tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                                   __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
+            tmax = __builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
+        } else {
+            tmin = max_msl(max_msl(min_msl(t0x, t1x), min_msl(t0y, t1y)), max_msl(min_msl(t0z, t1z), 0.0f));
+            tmax = min_msl(min_msl(max_msl(t0x, t1x), max_msl(t0y, t1y)), min_msl(max_msl(t0z, t1z), __builtin_inff()));
+        }
         if (tmin <= tmax && tmin < best.t) {
             const int left = __float_as_int(lo.w), right = __float_as_int(hi.w);
             if (right == 0) {
@@ -81,7 +96,7 @@ __device__ __forceinline__ Hit closest_hit(const BvhLds& s, const BvhView& b, V3
             } else {
                 for (int i = left; i < right; i++) {   // trace.metal:161-172
                     float4 a0, a1, a2;
-                    if (b.lds_tris) { a0 = s.tris[3 * i]; a1 = s.tris[3 * i + 1]; a2 = s.tris[3 * i + 2]; }
+                    if (ALL_LDS || b.lds_tris) { a0 = s.tris[3 * i]; a1 = s.tris[3 * i + 1]; a2 = s.tris[3 * i + 2]; }
                     else { a0 = b.tris[3 * i]; a1 = b.tris[3 * i + 1]; a2 = b.tris[3 * i + 2]; }
                     if (COUNT) n_tri++;
                     // ray_triangle_intersect, trace.metal:117-142
@@ -103,6 +118,24 @@ __device__ __forceinline__ Hit closest_hit(const BvhLds& s, const BvhView& b, V3
         node = next;
     }
     return best;
+}
+
+__device__ __forceinline__ bool finite3(V3 a) {
+    return __builtin_fabsf(a.x) < __builtin_inff() && __builtin_fabsf(a.y) < __builtin_inff() && __builtin_fabsf(a.z) < __builtin_inff();
+}
+
+// Dispatch: wave-uniform choice of the slab-test form, block-uniform choice of the staging mode.
+template <bool COUNT>
+__device__ __forceinline__ Hit closest_hit(const BvhLds& s, const BvhView& b, V3 o, V3 d, V3 inv,
+                                          unsigned& n_box, unsigned& n_tri) {
+    const bool all_lds = b.lds_tris && b.n_nodes <= b.n_lds_nodes;
+    const bool fast = __all(finite3(inv));
+    if (all_lds) {
+        if (fast) return closest_hit_impl<COUNT, true, true>(s, b, o, d, inv, n_box, n_tri);
+        return closest_hit_impl<COUNT, true, false>(s, b, o, d, inv, n_box, n_tri);
+    }
+    if (fast) return closest_hit_impl<COUNT, false, true>(s, b, o, d, inv, n_box, n_tri);
+    return closest_hit_impl<COUNT, false, false>(s, b, o, d, inv, n_box, n_tri);
 }
 
 }  // namespace cl2
