@@ -32,6 +32,9 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_M
 def cpu_baseline(width, height, samples):
     """Oracle (kind 'port'): the CPU restatement of trace.metal's kernels + renderer.py's host glue,
     timed end to end on this host's cores.  Checker code used as the reported baseline only."""
+    # a GPU box exposes all host threads but grants a 16-CPU share: size the OpenMP team to it
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     import numpy as np
     import clive2_amd as c2
     from oracle import oracle as orc
@@ -42,9 +45,7 @@ def cpu_baseline(width, height, samples):
     for _ in range(samples):
         o.run_sample()
     dt = time.perf_counter() - t0
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    omp = os.environ.get("OMP_NUM_THREADS")
-    threads = int(omp) if omp else cores
+    threads = int(os.environ["OMP_NUM_THREADS"])
     return {"value": round(o.rays_traced / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"Cornell box {width}x{height}, {samples} sample(s) of the full BDPT pipeline "
                       f"({o.rays_traced} rays, {dt:.1f} s; C oracle, OpenMP)"}
@@ -59,8 +60,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-flags", type=int, default=0, help="performance experiments only (invalid renders)")
-    ap.add_argument("--cpu-width", type=int, default=960)
-    ap.add_argument("--cpu-height", type=int, default=540)
+    ap.add_argument("--cpu-width", type=int, default=1920)
+    ap.add_argument("--cpu-height", type=int, default=1080)
     ap.add_argument("--cpu-samples", type=int, default=1)
     args = ap.parse_args()
 

@@ -35,7 +35,7 @@ __device__ __forceinline__ void resolve_pair(
         // camera junction vertex t-1 and per-path camera tables (LDS)
         V3 c_o_in, V3 c_n_in, float c_c, float c_l, float c_tot_in, float c_cos_in, int c_tri, int c_meta,
         V3 prior_camera_color, const float* GCs, const float* RCs /* [m*BLOCK + tid] */,
-        unsigned long long mask, const float2* __restrict__ chit, const float4* __restrict__ tri_shade,
+        unsigned long long mask, float2 h, const float4* __restrict__ tri_shade,
         const MaterialDev* __restrict__ mats, const CameraRec& cam, V3 focal, V3 cam_dir,
         V3& total, float& contrib_weight_sum, float4* __restrict__ light_image, int debug_flags) {
     const int tid = threadIdx.x;
@@ -50,7 +50,6 @@ __device__ __forceinline__ void resolve_pair(
     } else {
         if (!((mask >> conn_slot(t, S)) & 1ull)) return;                      // culled in k_connect_setup
         const LightVtx& a = lv[S - 1];
-        const float2 h = chit[(size_t)conn_slot(t, S) * B + pid];
         const int best_i = __float_as_int(h.x);
         if (best_i == -1) return;                                             // :193 / :593
         if (t == 1) {
@@ -247,10 +246,15 @@ __global__ __launch_bounds__(BLOCK) void k_connect_resolve(
         const float c_cos = __builtin_fabsf(dot(v3(cP1), c_n));
         V3 prior_camera_color = v3(0, 0, 0);
         if (t >= 2) prior_camera_color = v3(cp.P3[ck - B]);
+        // all closest-hit results of this t in flight at once (entries of culled pairs are never used)
+        float2 hits[MAX_VERTS + 1];
+        hits[0] = make_float2(0.0f, 0.0f);
+#pragma unroll
+        for (int s = 1; s <= MAX_VERTS; s++) hits[s] = chit[(size_t)conn_slot(t, s) * B + pid];
 #define CL2_PAIR(S)                                                                                             \
         if ((S) <= Ll && t + (S) >= 2)                                                                          \
             resolve_pair<S>(t, B, pid, lv, GL, RL, l_spec, c_spec, spec7, c_o, c_n, cP0.w, cP1.w, cP3.w, c_cos, \
-                            c_tri, c_meta, prior_camera_color, GCs, RCs, mask, chit, tri_shade, mats, cam,     \
+                            c_tri, c_meta, prior_camera_color, GCs, RCs, mask, hits[S], tri_shade, mats, cam,  \
                             focal, cam_dir, total, contrib_weight_sum, light_image, debug_flags)
         CL2_PAIR(0); CL2_PAIR(1); CL2_PAIR(2); CL2_PAIR(3); CL2_PAIR(4); CL2_PAIR(5); CL2_PAIR(6);
 #undef CL2_PAIR

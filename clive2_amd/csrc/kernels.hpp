@@ -183,25 +183,57 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_paths(
 }
 
 // ---------------------------------------------------------------- K3 body: one bounce
+// FUSED: the launch also performs the closest-hit query of the level (k_trace_level); otherwise the
+// hit comes from a preceding k_traverse_paths launch.
 // trace.metal:417-516 for iteration `level` of the path loop.  `carry` holds new_ray's forward
 // importance (set by the previous iteration through next_ray, or by the generators).
-template <bool FROM_CAMERA>
+template <bool FROM_CAMERA, bool FUSED, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_bounce(
-        int level, int last, const int* __restrict__ queue_in, const unsigned* __restrict__ count_in,
-        int* __restrict__ queue_out, unsigned* __restrict__ count_out, int B, PathBufs pb,
-        const float4* __restrict__ hit, uint2* __restrict__ seeds,
+        BvhView bvh, Stats* stats, int level, int last, const int* __restrict__ queue_in,
+        const unsigned* __restrict__ count_in, int* __restrict__ queue_out, unsigned* __restrict__ count_out, int B,
+        PathBufs pb, const float4* __restrict__ hit, uint2* __restrict__ seeds,
         const float4* __restrict__ tri_shade, const MaterialDev* __restrict__ mats) {
     const unsigned n = *count_in;
     const unsigned j = blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = j < n;
     bool alive = false;
     int pid = 0;
-    if (j < n) {
+    size_t cur = 0;
+    float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, h = make_float4(__int_as_float(-1), 0, 0, 0);
+    if (active) {
         pid = queue_in ? queue_in[j] : (int)j;
-        const float4 h = hit[pid];
+        cur = (size_t)level * B + pid;
+        p0 = pb.P0[cur];
+        p1 = pb.P1[cur];
+    }
+    if constexpr (FUSED) {
+        // closest hit of the subpath ray (trace.metal:409-415) in the same launch: the hit record
+        // never goes through HBM and the ray is read once.
+        __shared__ BvhLds lds;
+        stage_bvh(lds, bvh);
+        unsigned nb = 0, nt = 0;
+        if (active) {
+            const V3 d = v3(p1);
+            const Hit hh = closest_hit<COUNT>(lds, bvh, v3(p0), d, rcp3(d), nb, nt);
+            h = make_float4(__int_as_float(hh.tri), hh.t, hh.u, hh.v);
+        }
+        if (COUNT) {
+            for (int off = 32; off > 0; off >>= 1) { nb += __shfl_down(nb, off); nt += __shfl_down(nt, off); }
+            if (lane_id() == 0) {
+                atomicAdd(&stats->box_tests, (unsigned long long)nb);
+                atomicAdd(&stats->tri_tests, (unsigned long long)nt);
+            }
+        }
+        if (j == 0) {
+            atomicAdd(&stats->rays, (unsigned long long)n);
+            if (COUNT) atomicAdd(&stats->counted_rays, (unsigned long long)n);
+        }
+    } else {
+        if (active) h = hit[pid];
+    }
+    if (active) {
         const int best_i = __float_as_int(h.x);
         if (best_i != -1) {
-            const size_t cur = (size_t)level * B + pid;
-            float4 p0 = pb.P0[cur], p1 = pb.P1[cur];
             const float4 p3 = pb.P3[cur];
             const float best_t = h.y, u = h.z, v = h.w;
             const float4 s0 = tri_shade[4 * best_i], s1 = tri_shade[4 * best_i + 1],
@@ -302,13 +334,13 @@ __device__ __forceinline__ bool conn_ray(int t, const ConnVtx& lv, const ConnVtx
     return true;
 }
 
-// Enumerate strategy pairs per pixel, emit connection rays into a compacted queue.
-// Rays are ordered wave-by-wave, slot-major inside a wave, so consecutive queue entries come from
-// the same (t,s) strategy of neighbouring pixels.
+// Enumerate strategy pairs per pixel, emit connection rays into a compacted queue of 4-byte tags
+// {slot, pixel}.  Tags are ordered wave-by-wave, slot-major inside a wave, so consecutive queue
+// entries are the same (t,s) strategy of neighbouring pixels: the vertex gathers of
+// k_traverse_conn are coalesced and its rays coherent.
 __global__ __launch_bounds__(BLOCK) void k_connect_setup(
         int B, PathBufs lp, PathBufs cp, const MaterialDev* __restrict__ mats, CameraRec cam,
-        float4* __restrict__ cray0, float4* __restrict__ cray1, unsigned* __restrict__ ccount,
-        unsigned long long* __restrict__ cmask) {
+        int* __restrict__ ctag, unsigned* __restrict__ ccount, unsigned long long* __restrict__ cmask) {
     __shared__ unsigned s_wave_total[WAVES_PER_BLOCK];
     __shared__ unsigned s_base;
     const int pid = blockIdx.x * BLOCK + threadIdx.x;
@@ -354,46 +386,43 @@ __global__ __launch_bounds__(BLOCK) void k_connect_setup(
     unsigned running = s_base;
     for (int w = 0; w < wave; w++) running += s_wave_total[w];
     if (valid) cmask[pid] = mine;
-    // pass 2: write rays
+    // pass 2: write the ray tags {slot, pixel}; k_traverse_conn rebuilds the ray from the two vertices
 #pragma unroll
     for (int t = 1; t <= MAX_VERTS; t++) {
-        ConnVtx cv{v3(0, 0, 0), v3(0, 0, 0), 0};
-        if (t <= Lc) {
-            const float4 a = cp.P0[(size_t)(t - 1) * B + pid], c = cp.P2[(size_t)(t - 1) * B + pid];
-            cv = ConnVtx{v3(a), v3(c), __float_as_int(c.w)};
-        }
 #pragma unroll
         for (int s = 1; s <= MAX_VERTS; s++) {
             const int slot = conn_slot(t, s);
             const bool pred = (mine >> slot) & 1ull;
             const unsigned long long m = __ballot(pred);
-            if (pred) {
-                V3 dir;
-                conn_ray(t, lv[s - 1], cv, mats, focal, cam_dir, dir);
-                const unsigned idx = running + __popcll(m & ((1ull << lane) - 1ull));
-                cray0[idx] = f4(lv[s - 1].o, __int_as_float((slot << TAG_PID_BITS) | pid));
-                cray1[idx] = f4(dir, 0.0f);
-            }
+            if (pred) ctag[running + __popcll(m & ((1ull << lane) - 1ull))] = (slot << TAG_PID_BITS) | pid;
             running += __popcll(m);
         }
     }
 }
 
 // Closest hit for each connection ray; result scattered to chit[slot*B + pid] = {tri, t}.
+// The ray of tag {slot=(t,s), pixel} starts at light vertex s-1 and points at the focal point
+// (t == 1: projection onto the film, trace.metal:580-585) or at camera vertex t-1
+// (visibility_test, trace.metal:180-184).
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_traverse_conn(
-        BvhView bvh, int B, const unsigned* __restrict__ count, const float4* __restrict__ cray0,
-        const float4* __restrict__ cray1, float2* __restrict__ chit, Stats* stats) {
+        BvhView bvh, int B, const unsigned* __restrict__ count, const int* __restrict__ ctag,
+        const float4* __restrict__ LP0, const float4* __restrict__ CP0, CameraRec cam,
+        float2* __restrict__ chit, Stats* stats) {
     __shared__ BvhLds lds;
     stage_bvh(lds, bvh);
     const unsigned n = *count;
+    const V3 focal = cam3(cam.focal_point);
     unsigned nb = 0, nt = 0;
     for (unsigned j = blockIdx.x * BLOCK + threadIdx.x; j < n; j += gridDim.x * BLOCK) {
-        const float4 a = cray0[j], b4 = cray1[j];
-        const V3 o = v3(a), d = v3(b4);
-        const int tag = __float_as_int(a.w);
-        const Hit h = closest_hit<COUNT>(lds, bvh, o, d, rcp3(d), nb, nt);
+        const int tag = ctag[j];
         const int pid = tag & ((1 << TAG_PID_BITS) - 1), slot = (unsigned)tag >> TAG_PID_BITS;
+        const int t = slot / 6 + 1, s = slot % 6 + 1;
+        const V3 o = v3(LP0[(size_t)(s - 1) * B + pid]);
+        V3 target = focal;
+        if (t > 1) target = v3(CP0[(size_t)(t - 1) * B + pid]);
+        const V3 d = normalize(target - o);
+        const Hit h = closest_hit<COUNT>(lds, bvh, o, d, rcp3(d), nb, nt);
         chit[(size_t)slot * B + pid] = make_float2(__int_as_float(h.tri), h.t);
     }
     if (COUNT) {

@@ -60,8 +60,7 @@ struct cl2_renderer {
     float4* d_hit = nullptr;
     int* d_queue = nullptr;            // [6][B], shared by both subpath kinds (they run one after the other)
     unsigned* d_qcount = nullptr;      // [8]: [0] = B (level-0 count), [1..6] level counts, [7] connection rays
-    float4 *d_cray0 = nullptr, *d_cray1 = nullptr;
-    size_t cray_cap = 0;
+    int* d_ctag = nullptr;             // connection-ray queue: {slot, pixel} tags
     float2* d_chit = nullptr;
     unsigned long long* d_cmask = nullptr;
     float* d_agg = nullptr;
@@ -164,27 +163,16 @@ int launch_trace(cl2_renderer* r, int which) {
         const unsigned* c_in = r->d_qcount + level;            // [0] holds B
         int* q_out = r->d_queue + (size_t)level * B;
         unsigned* c_out = r->d_qcount + level + 1;
-        {
-            Timed t(r, ST_TRAVERSE_PATHS);
-            if (r->counting)
-                hipLaunchKernelGGL(k_traverse_paths<true>, dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, r->bvh, q_in, c_in,
-                                   pb.P0 + (size_t)level * B, pb.P1 + (size_t)level * B, r->d_hit, r->d_stats);
-            else
-                hipLaunchKernelGGL(k_traverse_paths<false>, dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, r->bvh, q_in, c_in,
-                                   pb.P0 + (size_t)level * B, pb.P1 + (size_t)level * B, r->d_hit, r->d_stats);
-            r->launches_tp++;
-        }
-        HIP_TRY(r, hipGetLastError());
-        {
-            Timed t(r, ST_BOUNCE);
-            const int last = level == MAX_VERTS - 1;
-            if (which == CL2_CAMERA)
-                hipLaunchKernelGGL(k_bounce<true>, dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, level, last, q_in, c_in, q_out,
-                                   c_out, B, pb, r->d_hit, r->d_seeds, r->d_tri_shade, r->d_mats);
-            else
-                hipLaunchKernelGGL(k_bounce<false>, dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, level, last, q_in, c_in, q_out,
-                                   c_out, B, pb, r->d_hit, r->d_seeds, r->d_tri_shade, r->d_mats);
-        }
+        const int last = level == MAX_VERTS - 1;
+        // one launch per level: closest hit + bounce (timed under the traverse_paths stage)
+        Timed t(r, ST_TRAVERSE_PATHS);
+#define CL2_TRACE(CAM, CNT)                                                                                              \
+        hipLaunchKernelGGL((k_bounce<CAM, true, CNT>), dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, r->bvh, r->d_stats, level, \
+                           last, q_in, c_in, q_out, c_out, B, pb, r->d_hit, r->d_seeds, r->d_tri_shade, r->d_mats)
+        if (which == CL2_CAMERA) { if (r->counting) CL2_TRACE(true, true); else CL2_TRACE(true, false); }
+        else { if (r->counting) CL2_TRACE(false, true); else CL2_TRACE(false, false); }
+#undef CL2_TRACE
+        r->launches_tp++;
         HIP_TRY(r, hipGetLastError());
     }
     return CL2_OK;
@@ -196,7 +184,7 @@ int launch_join(cl2_renderer* r) {
     {
         Timed t(r, ST_CONNECT_SETUP);
         hipLaunchKernelGGL(k_connect_setup, dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, B, r->pb[CL2_LIGHT], r->pb[CL2_CAMERA],
-                           r->d_mats, r->cam, r->d_cray0, r->d_cray1, r->d_qcount + 7, r->d_cmask);
+                           r->d_mats, r->cam, r->d_ctag, r->d_qcount + 7, r->d_cmask);
     }
     HIP_TRY(r, hipGetLastError());
     {
@@ -204,11 +192,11 @@ int launch_join(cl2_renderer* r) {
         // grid-stride over the (device-side) ray count; enough workgroups to fill 256 CUs several times over
         const int grid = std::min<size_t>(grid_for((size_t)B * 8), 256 * 32);
         if (r->counting)
-            hipLaunchKernelGGL(k_traverse_conn<true>, dim3(grid), dim3(BLOCK), 0, r->stream, r->bvh, B, r->d_qcount + 7, r->d_cray0,
-                               r->d_cray1, r->d_chit, r->d_stats);
+            hipLaunchKernelGGL(k_traverse_conn<true>, dim3(grid), dim3(BLOCK), 0, r->stream, r->bvh, B, r->d_qcount + 7, r->d_ctag,
+                               r->pb[CL2_LIGHT].P0, r->pb[CL2_CAMERA].P0, r->cam, r->d_chit, r->d_stats);
         else
-            hipLaunchKernelGGL(k_traverse_conn<false>, dim3(grid), dim3(BLOCK), 0, r->stream, r->bvh, B, r->d_qcount + 7, r->d_cray0,
-                               r->d_cray1, r->d_chit, r->d_stats);
+            hipLaunchKernelGGL(k_traverse_conn<false>, dim3(grid), dim3(BLOCK), 0, r->stream, r->bvh, B, r->d_qcount + 7, r->d_ctag,
+                               r->pb[CL2_LIGHT].P0, r->pb[CL2_CAMERA].P0, r->cam, r->d_chit, r->d_stats);
         r->launches_tc++;
     }
     HIP_TRY(r, hipGetLastError());
@@ -294,8 +282,7 @@ int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_render
     A(r->d_hit, B);
     A(r->d_queue, MAX_VERTS * B);
     A(r->d_qcount, 8);
-    r->cray_cap = (size_t)CONN_SLOTS * B;
-    A(r->d_cray0, r->cray_cap); A(r->d_cray1, r->cray_cap);
+    A(r->d_ctag, (size_t)CONN_SLOTS * B);
     A(r->d_chit, (size_t)CONN_SLOTS * B);
     A(r->d_cmask, B);
     A(r->d_agg, (size_t)AGG_ROWS * B);

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# The oracle is OpenMP code; a GPU box exposes every host thread but grants a 16-CPU share, and
+# oversubscribed spinning OpenMP teams are pathologically slow.
+os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
