@@ -167,7 +167,8 @@ __device__ __forceinline__ void resolve_pair(
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_connect_resolve(
+template <int WAVES_PER_SIMD>
+__global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
         int B, PathBufs lp, PathBufs cp, const MaterialDev* __restrict__ mats,
         const float4* __restrict__ tri_shade, CameraRec cam, const unsigned long long* __restrict__ cmask,
         const float2* __restrict__ chit, float* __restrict__ agg, float4* __restrict__ light_image,

@@ -264,9 +264,16 @@ __global__ __launch_bounds__(BLOCK) void k_bounce(
                 const float ryb = xorshift_random(sd.y);
                 seeds[pid] = sd;
 
-                const V3 m = GGX_sample(nrm, rxa, rya, alpha);
+                // Microfacet normal (:466).  For a smooth Lambertian surface (alpha == 0, type 0) GGX_sample
+                // reduces exactly to normalize(n): phi = atan(0) = 0, so m = normalize(0*x + 0*y + 1*n), and m
+                // only feeds the two sign tests below, which ignore the sign of a zero component.  The draw
+                // ry == 1 (0/0 -> NaN) keeps the general route.
+                V3 m;
+                if (mtype == 0 && alpha == 0.0f && rya != 1.0f) m = normalize(nrm);
+                else m = GGX_sample(nrm, rxa, rya, alpha);
                 if (!(dot(wi, m) < 0.0f) && !(dot(m, nrm) < 0.0f)) {
-                    const float fresnel = degreve_fresnel(wi, m, ni, no);
+                    float fresnel = 0.0f;                                  // only types 1 and 2 read it (:476-485)
+                    if (mtype != 0) fresnel = degreve_fresnel(wi, m, ni, no);
                     Bounce b;
                     if (mtype == 0) b = diffuse_bounce(wi, nrm, FROM_CAMERA, rxb, ryb);
                     else if (mtype == 1) {

@@ -202,8 +202,13 @@ int launch_join(cl2_renderer* r) {
     HIP_TRY(r, hipGetLastError());
     {
         Timed t(r, ST_CONNECT_RESOLVE);
-        hipLaunchKernelGGL(k_connect_resolve, dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, B, r->pb[CL2_LIGHT], r->pb[CL2_CAMERA],
-                           r->d_mats, r->d_tri_shade, r->cam, r->d_cmask, r->d_chit, r->d_agg, r->d_light_image, r->d_uni, r->d_stats, r->debug_flags);
+#define CL2_RESOLVE(W)                                                                                                       \
+        hipLaunchKernelGGL(k_connect_resolve<W>, dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, B, r->pb[CL2_LIGHT],             \
+                           r->pb[CL2_CAMERA], r->d_mats, r->d_tri_shade, r->cam, r->d_cmask, r->d_chit, r->d_agg,               \
+                           r->d_light_image, r->d_uni, r->d_stats, r->debug_flags)
+        const int occ = (r->debug_flags >> 4) & 7;      // experiment switch: register budget of the resolve kernel
+        if (occ == 3) CL2_RESOLVE(3); else if (occ == 4) CL2_RESOLVE(4); else CL2_RESOLVE(2);
+#undef CL2_RESOLVE
     }
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;
