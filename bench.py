@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-flags", type=int, default=0, help="performance experiments only (invalid renders)")
+    ap.add_argument("--levels-per-launch", type=int, default=6, help="subpath bounces per launch (1..6)")
     ap.add_argument("--cpu-width", type=int, default=1920)
     ap.add_argument("--cpu-height", type=int, default=1080)
     ap.add_argument("--cpu-samples", type=int, default=1)
@@ -95,6 +96,8 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    r.set_levels_per_launch(args.levels_per_launch)
 
     # untimed: warm-up (also the counting pass that measures N_node / N_tri per ray)
     r.set_counting(True)

@@ -39,6 +39,7 @@ constexpr int WAVES_PER_BLOCK = BLOCK / 64;
 constexpr int MAX_VERTS = 6;          // bounce loop bound, trace.metal:407
 constexpr int CONN_SLOTS = 36;        // (t in 1..6) x (s in 1..6) strategy pairs that need a ray
 constexpr int TAG_PID_BITS = 26;
+constexpr int LDS_MAT_CAP = 32;      // materials staged in LDS by the subpath kernel
 constexpr int META_HIT_LIGHT = 1 << 8;
 constexpr int META_HIT_CAMERA = 1 << 9;
 
@@ -182,138 +183,191 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_paths(
     }
 }
 
-// ---------------------------------------------------------------- K3 body: one bounce
-// FUSED: the launch also performs the closest-hit query of the level (k_trace_level); otherwise the
-// hit comes from a preceding k_traverse_paths launch.
-// trace.metal:417-516 for iteration `level` of the path loop.  `carry` holds new_ray's forward
-// importance (set by the previous iteration through next_ray, or by the generators).
-template <bool FROM_CAMERA, bool FUSED, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_bounce(
-        BvhView bvh, Stats* stats, int level, int last, const int* __restrict__ queue_in,
+// ---------------------------------------------------------------- K3: generate_paths, levels [first, end)
+// trace.metal:407-516 for the iterations first..end-1 of the path loop, one thread per queued path.
+//
+// The launch keeps the walking state (current vertex, RNG, carried pdf) in registers across its
+// levels: a vertex is written to HBM once, complete, when its reverse pdf becomes known one level
+// later (the reference's `path.rays[i] = ray`, :512), instead of being written, re-read and patched
+// by consecutive launches.  Survivors of the last level are compacted into `queue_out` (wave
+// ballots, one atomic per workgroup) for the next launch.  The host chooses the segmentation:
+// [0,6) in one launch when nearly every path survives (closed scenes: compaction buys nothing),
+// one level per launch when paths die quickly (open scenes, glass).
+//
+// Vertices `first` (written by the generator or the previous launch) is patched in place; the vertex
+// created at level end-1 is written complete (reverse pdf still open) when the path goes on.
+struct ShadeLds {
+    float4 tri_shade[4 * LDS_TRI_CAP];
+    MaterialDev mats[LDS_MAT_CAP];
+};
+
+template <bool FROM_CAMERA, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_trace_subpath(
+        BvhView bvh, Stats* stats, int first, int end, const int* __restrict__ queue_in,
         const unsigned* __restrict__ count_in, int* __restrict__ queue_out, unsigned* __restrict__ count_out, int B,
-        PathBufs pb, const float4* __restrict__ hit, uint2* __restrict__ seeds,
-        const float4* __restrict__ tri_shade, const MaterialDev* __restrict__ mats) {
+        PathBufs pb, uint2* __restrict__ seeds, const float4* __restrict__ tri_shade_g,
+        const MaterialDev* __restrict__ mats_g, int n_mats, unsigned long long* __restrict__ block_stats) {
+    __shared__ BvhLds lds;
+    __shared__ ShadeLds sh;
+    const bool shade_lds = bvh.lds_tris != 0, mats_lds = n_mats <= LDS_MAT_CAP;
+    if (shade_lds) for (int i = threadIdx.x; i < 4 * bvh.n_tris; i += BLOCK) sh.tri_shade[i] = tri_shade_g[i];
+    if (mats_lds) for (int i = threadIdx.x; i < n_mats; i += BLOCK) sh.mats[i] = mats_g[i];
+    stage_bvh(lds, bvh);                                   // ends with the barrier
+
     const unsigned n = *count_in;
     const unsigned j = blockIdx.x * BLOCK + threadIdx.x;
-    const bool active = j < n;
-    bool alive = false;
+    bool alive = j < n;
     int pid = 0;
-    size_t cur = 0;
-    float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, h = make_float4(__int_as_float(-1), 0, 0, 0);
-    if (active) {
+    // current vertex (the reference's `ray`) and what it needs to be stored complete
+    V3 ro = v3(0, 0, 0), rd = ro, rn = ro, rcol = ro;
+    float r_c = 0.0f, r_l = 0.0f, r_tot = 0.0f, fwd = 0.0f;
+    int r_meta = 0, r_tri = -1;
+    uint2 sd = make_uint2(0, 0);
+    bool seeds_dirty = false;
+    int stored = -1;                                       // index of the last vertex stored by this launch
+    if (alive) {
         pid = queue_in ? queue_in[j] : (int)j;
-        cur = (size_t)level * B + pid;
-        p0 = pb.P0[cur];
-        p1 = pb.P1[cur];
+        const size_t cur = (size_t)first * B + pid;
+        const float4 p0 = pb.P0[cur], p1 = pb.P1[cur], p3 = pb.P3[cur];
+        ro = v3(p0); rd = v3(p1); rcol = v3(p3);
+        r_c = p0.w; r_l = p1.w; r_tot = p3.w;
+        fwd = pb.carry[pid];
+        sd = seeds[pid];
     }
-    if constexpr (FUSED) {
-        // closest hit of the subpath ray (trace.metal:409-415) in the same launch: the hit record
-        // never goes through HBM and the ray is read once.
-        __shared__ BvhLds lds;
-        stage_bvh(lds, bvh);
-        unsigned nb = 0, nt = 0;
-        if (active) {
-            const V3 d = v3(p1);
-            const Hit hh = closest_hit<COUNT>(lds, bvh, v3(p0), d, rcp3(d), nb, nt);
-            h = make_float4(__int_as_float(hh.tri), hh.t, hh.u, hh.v);
-        }
-        if (COUNT) {
-            for (int off = 32; off > 0; off >>= 1) { nb += __shfl_down(nb, off); nt += __shfl_down(nt, off); }
-            if (lane_id() == 0) {
-                atomicAdd(&stats->box_tests, (unsigned long long)nb);
-                atomicAdd(&stats->tri_tests, (unsigned long long)nt);
-            }
-        }
-        if (j == 0) {
-            atomicAdd(&stats->rays, (unsigned long long)n);
-            if (COUNT) atomicAdd(&stats->counted_rays, (unsigned long long)n);
-        }
-    } else {
-        if (active) h = hit[pid];
-    }
-    if (active) {
-        const int best_i = __float_as_int(h.x);
-        if (best_i != -1) {
-            const float4 p3 = pb.P3[cur];
-            const float best_t = h.y, u = h.z, v = h.w;
-            const float4 s0 = tri_shade[4 * best_i], s1 = tri_shade[4 * best_i + 1],
-                         s2 = tri_shade[4 * best_i + 2], s3 = tri_shade[4 * best_i + 3];
-            const int material = __float_as_int(s0.w);
-            const bool is_light = __float_as_int(s1.w) != 0, is_camera = __float_as_int(s2.w) != 0;
-            const MaterialDev mat = mats[material];
-            const int mtype = __float_as_int(mat.color_type.w);
-            const float alpha = mat.emission_alpha.w;
-            const V3 tn = v3(s3), rd = v3(p1), ro = v3(p0), rcol = v3(p3);
+    unsigned nb = 0, nt = 0, nrays = 0;
 
-            const V3 sn = normalize((v3(s0) * (1 - u - v) + v3(s1) * u) + v3(s2) * v);   // sample_normal :330-332
-            const float facing = dot(-rd, tn);
-            V3 nrm = sn;
-            float ni = 1.0f, no = mat.ior;
-            bool ok = true;
-            if (facing > 0) { }
-            else if (facing < 0) { nrm = -sn; ni = mat.ior; no = 1.0f; }
-            else ok = false;                                                           // :433-435
-            if (ok) {
-                const V3 new_origin = ro + rd * best_t;
-                const bool hit_light = is_light && dot(rd, tn) < 0.0f;
-                const V3 wi = -rd;
-                uint2 sd = seeds[pid];
-                const float rxa = xorshift_random(sd.x);
-                const float rya = xorshift_random(sd.y);
-                const float rxb = xorshift_random(sd.x);
-                const float ryb = xorshift_random(sd.y);
-                seeds[pid] = sd;
+    for (int level = first; level < end; level++) {
+        if (!__any(alive)) break;
+        bool go_on = false;
+        V3 n_o = ro, n_d = rd, n_n = rn, n_col = rcol;
+        float n_tot = 0.0f, next_fwd = 0.0f;
+        int n_meta = 0, n_tri = -1;
+        if (alive) {
+            nrays++;
+            const Hit hh = closest_hit<COUNT>(lds, bvh, ro, rd, rcp3(rd), nb, nt);     // :409-415
+            const int best_i = hh.tri;
+            if (best_i != -1) {
+                const float best_t = hh.t, u = hh.u, v = hh.v;
+                float4 s0, s1, s2, s3;
+                if (shade_lds) { s0 = sh.tri_shade[4 * best_i]; s1 = sh.tri_shade[4 * best_i + 1]; s2 = sh.tri_shade[4 * best_i + 2]; s3 = sh.tri_shade[4 * best_i + 3]; }
+                else { s0 = tri_shade_g[4 * best_i]; s1 = tri_shade_g[4 * best_i + 1]; s2 = tri_shade_g[4 * best_i + 2]; s3 = tri_shade_g[4 * best_i + 3]; }
+                const int material = __float_as_int(s0.w);
+                const bool is_light = __float_as_int(s1.w) != 0, is_camera = __float_as_int(s2.w) != 0;
+                const MaterialDev mat = mats_lds ? sh.mats[material] : mats_g[material];
+                const int mtype = __float_as_int(mat.color_type.w);
+                const float alpha = mat.emission_alpha.w;
+                const V3 tn = v3(s3);
 
-                // Microfacet normal (:466).  For a smooth Lambertian surface (alpha == 0, type 0) GGX_sample
-                // reduces exactly to normalize(n): phi = atan(0) = 0, so m = normalize(0*x + 0*y + 1*n), and m
-                // only feeds the two sign tests below, which ignore the sign of a zero component.  The draw
-                // ry == 1 (0/0 -> NaN) keeps the general route.
-                V3 m;
-                if (mtype == 0 && alpha == 0.0f && rya != 1.0f) m = normalize(nrm);
-                else m = GGX_sample(nrm, rxa, rya, alpha);
-                if (!(dot(wi, m) < 0.0f) && !(dot(m, nrm) < 0.0f)) {
-                    float fresnel = 0.0f;                                  // only types 1 and 2 read it (:476-485)
-                    if (mtype != 0) fresnel = degreve_fresnel(wi, m, ni, no);
-                    Bounce b;
-                    if (mtype == 0) b = diffuse_bounce(wi, nrm, FROM_CAMERA, rxb, ryb);
-                    else if (mtype == 1) {
-                        if (rxb <= fresnel) b = reflect_bounce(wi, nrm, m, ni, no, alpha, FROM_CAMERA);
-                        else b = transmit_bounce(wi, nrm, m, ni, no, alpha, FROM_CAMERA);
-                    } else if (mtype == 2) {
-                        if (rxb <= fresnel) b = reflect_bounce(wi, nrm, m, ni, no, alpha, FROM_CAMERA);
-                        else b = diffuse_bounce(wi, nrm, FROM_CAMERA, rxb, ryb);
-                    } else b = reflect_bounce(wi, nrm, m, ni, no, alpha, FROM_CAMERA);
+                const V3 sn = normalize((v3(s0) * (1 - u - v) + v3(s1) * u) + v3(s2) * v);   // sample_normal :330-332
+                const float facing = dot(-rd, tn);
+                V3 nrm = sn;
+                float ni = 1.0f, no = mat.ior;
+                bool ok = true;
+                if (facing > 0) { }
+                else if (facing < 0) { nrm = -sn; ni = mat.ior; no = 1.0f; }
+                else ok = false;                                                           // :433-435
+                if (ok) {
+                    const bool hit_light = is_light && dot(rd, tn) < 0.0f;
+                    const V3 wi = -rd;
+                    const float rxa = xorshift_random(sd.x);
+                    const float rya = xorshift_random(sd.y);
+                    const float rxb = xorshift_random(sd.x);
+                    const float ryb = xorshift_random(sd.y);
+                    seeds_dirty = true;
 
-                    const float wi_n = dot(wi, tn), wo_n = dot(b.wo, tn);
-                    V3 ncol = b.f * rcol;
-                    if ((wi_n > 0.0f && wo_n > 0.0f) || (wi_n < 0.0f && wo_n > 0.0f)) ncol = ncol * v3(mat.color_type);
+                    // Microfacet normal (:466).  For a smooth Lambertian surface (alpha == 0, type 0) GGX_sample
+                    // reduces exactly to normalize(n): phi = atan(0) = 0, so m = normalize(0*x + 0*y + 1*n), and m
+                    // only feeds the two sign tests below, which ignore the sign of a zero component.  The draw
+                    // ry == 1 (0/0 -> NaN) keeps the general route.
+                    V3 m;
+                    if (mtype == 0 && alpha == 0.0f && rya != 1.0f) m = normalize(nrm);
+                    else m = GGX_sample(nrm, rxa, rya, alpha);
+                    if (!(dot(wi, m) < 0.0f) && !(dot(m, nrm) < 0.0f)) {
+                        float fresnel = 0.0f;                                  // only types 1 and 2 read it (:476-485)
+                        if (mtype != 0) fresnel = degreve_fresnel(wi, m, ni, no);
+                        Bounce b;
+                        if (mtype == 0) b = diffuse_bounce(wi, nrm, FROM_CAMERA, rxb, ryb);
+                        else if (mtype == 1) {
+                            if (rxb <= fresnel) b = reflect_bounce(wi, nrm, m, ni, no, alpha, FROM_CAMERA);
+                            else b = transmit_bounce(wi, nrm, m, ni, no, alpha, FROM_CAMERA);
+                        } else if (mtype == 2) {
+                            if (rxb <= fresnel) b = reflect_bounce(wi, nrm, m, ni, no, alpha, FROM_CAMERA);
+                            else b = diffuse_bounce(wi, nrm, FROM_CAMERA, rxb, ryb);
+                        } else b = reflect_bounce(wi, nrm, m, ni, no, alpha, FROM_CAMERA);
 
-                    const float fwd = pb.carry[pid];            // new_ray.{c,l}_importance
-                    const float new_tot = p3.w * fwd;           // :502 / :506
-                    if (!(b.f == 0.0f)) {                       // :509
-                        // path.rays[level] = ray, with its reverse pdf now known (:501 / :505)
-                        if (FROM_CAMERA) { p1.w = b.l_p; pb.P1[cur] = p1; }
-                        else { p0.w = b.c_p; pb.P0[cur] = p0; }
-                        pb.len[pid] = level + 1;
-                        if (!last) {
-                            const size_t nxt = cur + B;
-                            const int meta = material | (hit_light ? META_HIT_LIGHT : 0) | (is_camera ? META_HIT_CAMERA : 0);
-                            pb.P0[nxt] = f4(new_origin, FROM_CAMERA ? fwd : 0.0f);
-                            pb.P1[nxt] = f4(b.wo, FROM_CAMERA ? 0.0f : fwd);
-                            pb.P2[nxt] = f4(nrm, __int_as_float(meta));
-                            pb.P3[nxt] = f4(ncol, new_tot);
-                            pb.tri[nxt] = best_i;
-                            pb.carry[pid] = FROM_CAMERA ? b.c_p : b.l_p;   // next_ray, :500 / :504
-                            alive = true;
+                        const float wi_n = dot(wi, tn), wo_n = dot(b.wo, tn);
+                        V3 ncol = b.f * rcol;
+                        if ((wi_n > 0.0f && wo_n > 0.0f) || (wi_n < 0.0f && wo_n > 0.0f)) ncol = ncol * v3(mat.color_type);
+
+                        if (!(b.f == 0.0f)) {                       // :509
+                            // path.rays[level] = ray, its reverse pdf now known (:501 / :505, :512)
+                            if (FROM_CAMERA) r_l = b.l_p; else r_c = b.c_p;
+                            const size_t cur = (size_t)level * B + pid;
+                            if (level == first) {
+                                if (FROM_CAMERA) pb.P1[cur] = f4(rd, r_l); else pb.P0[cur] = f4(ro, r_c);
+                            } else {
+                                pb.P0[cur] = f4(ro, r_c);
+                                pb.P1[cur] = f4(rd, r_l);
+                                pb.P2[cur] = f4(rn, __int_as_float(r_meta));
+                                pb.P3[cur] = f4(rcol, r_tot);
+                                pb.tri[cur] = r_tri;
+                            }
+                            stored = level;
+                            // new_ray (:437-449, :496-506) becomes the current vertex of the next level
+                            n_o = ro + rd * best_t;
+                            n_d = b.wo; n_n = nrm; n_col = ncol;
+                            n_tot = r_tot * fwd;                    // :502 / :506
+                            n_meta = material | (hit_light ? META_HIT_LIGHT : 0) | (is_camera ? META_HIT_CAMERA : 0);
+                            n_tri = best_i;
+                            next_fwd = FROM_CAMERA ? b.c_p : b.l_p; // next_ray, :500 / :504
+                            go_on = true;
                         }
                     }
                 }
             }
         }
+        if (go_on) {
+            ro = n_o; rd = n_d; rn = n_n; rcol = n_col;
+            r_c = FROM_CAMERA ? fwd : 0.0f;
+            r_l = FROM_CAMERA ? 0.0f : fwd;
+            r_tot = n_tot; r_meta = n_meta; r_tri = n_tri;
+            fwd = next_fwd;
+        }
+        alive = go_on;
     }
-    if (last) return;                                   // uniform: no queue after the final bounce
-    const unsigned idx = block_compact_index(alive, count_out);
-    if (alive) queue_out[idx] = pid;
+
+    if (stored >= 0) pb.len[pid] = stored + 1;
+    if (seeds_dirty) seeds[pid] = sd;
+    const bool hand_over = alive && end < MAX_VERTS;      // the path goes on in a later launch
+    if (hand_over) {
+        const size_t nxt = (size_t)end * B + pid;
+        pb.P0[nxt] = f4(ro, r_c);
+        pb.P1[nxt] = f4(rd, r_l);
+        pb.P2[nxt] = f4(rn, __int_as_float(r_meta));
+        pb.P3[nxt] = f4(rcol, r_tot);
+        pb.tri[nxt] = r_tri;
+        pb.carry[pid] = fwd;
+    }
+    // tallies: wave shuffle -> LDS -> one plain read-modify-write per workgroup into its own slot
+    // (a same-address atomic per wave costs ~0.4 ms per launch at 32k waves; launches on one stream
+    // are ordered, so the slot needs no atomic).  The host sums the slots.
+    for (int off = 32; off > 0; off >>= 1) {
+        nrays += __shfl_down(nrays, off);
+        if (COUNT) { nb += __shfl_down(nb, off); nt += __shfl_down(nt, off); }
+    }
+    __shared__ unsigned s_tally[WAVES_PER_BLOCK][3];
+    if (lane_id() == 0) { s_tally[threadIdx.x >> 6][0] = nrays; s_tally[threadIdx.x >> 6][1] = nb; s_tally[threadIdx.x >> 6][2] = nt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long tr = 0, tb = 0, tt = 0;
+        for (int w = 0; w < WAVES_PER_BLOCK; w++) { tr += s_tally[w][0]; tb += s_tally[w][1]; tt += s_tally[w][2]; }
+        unsigned long long* slot = block_stats + (size_t)blockIdx.x * 4;
+        slot[0] += tr;
+        if (COUNT) { slot[1] += tb; slot[2] += tt; slot[3] += tr; }
+    }
+    if (end >= MAX_VERTS) return;                          // uniform: no queue after the final bounce
+    const unsigned idx = block_compact_index(hand_over, count_out);
+    if (hand_over) queue_out[idx] = pid;
 }
 
 // ---------------------------------------------------------------- connection stage

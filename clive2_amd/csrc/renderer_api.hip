@@ -44,6 +44,7 @@ struct cl2_renderer {
     std::string err;
     bool scene_ok = false, profiling = false, counting = false;
     int debug_flags = 0;
+    int levels_per_launch = MAX_VERTS;   // subpath levels per launch (6 = one launch, 1 = compaction after every bounce)
 
     // scene
     BvhView bvh{};
@@ -68,6 +69,7 @@ struct cl2_renderer {
     float* d_sample_w = nullptr;
     float* d_acc = nullptr;            // [8][B]
     Stats* d_stats = nullptr;
+    unsigned long long* d_block_stats = nullptr;   // [grid][4]: rays, box tests, tri tests, counted rays per workgroup slot
 
     // host-side tallies
     uint64_t samples = 0, counted_rays = 0;
@@ -158,17 +160,18 @@ int launch_trace(cl2_renderer* r, int which) {
     const int B = r->B;
     PathBufs pb = r->pb[which];
     HIP_TRY(r, hipMemsetAsync(r->d_qcount + 1, 0, 6 * sizeof(unsigned), r->stream));
-    for (int level = 0; level < MAX_VERTS; level++) {
-        const int* q_in = level == 0 ? nullptr : r->d_queue + (size_t)(level - 1) * B;
-        const unsigned* c_in = r->d_qcount + level;            // [0] holds B
-        int* q_out = r->d_queue + (size_t)level * B;
-        unsigned* c_out = r->d_qcount + level + 1;
-        const int last = level == MAX_VERTS - 1;
-        // one launch per level: closest hit + bounce (timed under the traverse_paths stage)
+    const int step = std::max(1, std::min(r->levels_per_launch, (int)MAX_VERTS));
+    for (int first = 0; first < MAX_VERTS; first += step) {
+        const int end = std::min(first + step, (int)MAX_VERTS);
+        // queue slot k holds the paths alive after level k-1 (slot 0 = everybody, count B)
+        const int* q_in = first == 0 ? nullptr : r->d_queue + (size_t)(first - 1) * B;
+        const unsigned* c_in = r->d_qcount + first;
+        int* q_out = r->d_queue + (size_t)(end - 1) * B;
+        unsigned* c_out = r->d_qcount + end;
         Timed t(r, ST_TRAVERSE_PATHS);
 #define CL2_TRACE(CAM, CNT)                                                                                              \
-        hipLaunchKernelGGL((k_bounce<CAM, true, CNT>), dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, r->bvh, r->d_stats, level, \
-                           last, q_in, c_in, q_out, c_out, B, pb, r->d_hit, r->d_seeds, r->d_tri_shade, r->d_mats)
+        hipLaunchKernelGGL((k_trace_subpath<CAM, CNT>), dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, r->bvh, r->d_stats, first, \
+                           end, q_in, c_in, q_out, c_out, B, pb, r->d_seeds, r->d_tri_shade, r->d_mats, r->n_mats, r->d_block_stats)
         if (which == CL2_CAMERA) { if (r->counting) CL2_TRACE(true, true); else CL2_TRACE(true, false); }
         else { if (r->counting) CL2_TRACE(false, true); else CL2_TRACE(false, false); }
 #undef CL2_TRACE
@@ -295,6 +298,7 @@ int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_render
     A(r->d_sample_w, B);
     A(r->d_acc, 8 * B);
     A(r->d_stats, 1);
+    A(r->d_block_stats, (size_t)grid_for(B) * 4);
 #undef A
     if (rc != CL2_OK) return bail(rc);
     unsigned qc[8] = {(unsigned)r->B, 0, 0, 0, 0, 0, 0, 0};
@@ -306,6 +310,7 @@ int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_render
     ok = ok && hipMemset(r->d_acc, 0, 8 * B * sizeof(float)) == hipSuccess;
     ok = ok && hipMemset(r->d_agg, 0, (size_t)AGG_ROWS * B * sizeof(float)) == hipSuccess;
     ok = ok && hipMemset(r->d_stats, 0, sizeof(Stats)) == hipSuccess;
+    ok = ok && hipMemset(r->d_block_stats, 0, (size_t)grid_for(B) * 4 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMemset(r->d_cmask, 0, B * sizeof(unsigned long long)) == hipSuccess;
     for (int k = 0; k < 2 && ok; k++) ok = hipMemset(r->pb[k].len, 0, B * sizeof(int)) == hipSuccess;
     // default seeds: 1 everywhere (xorshift's only forbidden state is 0); callers set real seeds
@@ -524,6 +529,9 @@ static int acc_copy(cl2_renderer* r, void* dst, const void* src, size_t n_floats
     HIP_TRY(r, hipSetDevice(r->device));
     HIP_TRY(r, hipStreamSynchronize(r->stream));
     HIP_TRY(r, hipMemcpy(dst, src, n_floats * sizeof(float), kind));
+    // a device-to-device hipMemcpy may return before it has run; the caller hands the buffer to RCCL
+    // (another stream) right away, so make it complete here
+    if (kind == hipMemcpyDeviceToDevice) HIP_TRY(r, hipDeviceSynchronize());
     return CL2_OK;
 }
 int cl2_read_accumulators_packed(cl2_renderer* r, float* dst, size_t n) { return acc_copy(r, dst, r ? r->d_acc : nullptr, n, hipMemcpyDeviceToHost); }
@@ -532,6 +540,12 @@ int cl2_copy_accumulators_to_device(cl2_renderer* r, void* dst, size_t n) { retu
 int cl2_copy_accumulators_from_device(cl2_renderer* r, const void* src, size_t n) { return acc_copy(r, r ? r->d_acc : nullptr, src, n, hipMemcpyDeviceToDevice); }
 
 int cl2_set_profiling(cl2_renderer* r, int on) { if (!r) return CL2_E_INVALID; r->profiling = on != 0; return CL2_OK; }
+int cl2_set_levels_per_launch(cl2_renderer* r, int levels) {
+    if (!r) return CL2_E_INVALID;
+    if (levels < 1 || levels > MAX_VERTS) return fail(r, CL2_E_INVALID, "levels_per_launch must be 1..6");
+    r->levels_per_launch = levels;
+    return CL2_OK;
+}
 int cl2_set_debug_flags(cl2_renderer* r, int flags) { if (!r) return CL2_E_INVALID; r->debug_flags = flags; return CL2_OK; }
 int cl2_set_counting(cl2_renderer* r, int on) { if (!r) return CL2_E_INVALID; r->counting = on != 0; return CL2_OK; }
 
@@ -541,6 +555,13 @@ int cl2_read_counters(cl2_renderer* r, cl2_counters* out) {
     TRY(drain(r));
     Stats s;
     HIP_TRY(r, hipMemcpy(&s, r->d_stats, sizeof s, hipMemcpyDeviceToHost));
+    {   // per-workgroup slots of the subpath kernel
+        std::vector<unsigned long long> slots((size_t)grid_for(r->B) * 4);
+        HIP_TRY(r, hipMemcpy(slots.data(), r->d_block_stats, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < slots.size(); b += 4) {
+            s.rays += slots[b]; s.box_tests += slots[b + 1]; s.tri_tests += slots[b + 2]; s.counted_rays += slots[b + 3];
+        }
+    }
     std::memset(out, 0, sizeof *out);
     out->rays = s.rays; out->conn_rays = s.conn_rays; out->box_tests = s.box_tests; out->tri_tests = s.tri_tests;
     out->counted_rays = s.counted_rays;
@@ -558,6 +579,7 @@ int cl2_reset_counters(cl2_renderer* r) {
     HIP_TRY(r, hipSetDevice(r->device));
     TRY(drain(r));
     HIP_TRY(r, hipMemset(r->d_stats, 0, sizeof(Stats)));
+    HIP_TRY(r, hipMemset(r->d_block_stats, 0, (size_t)grid_for(r->B) * 4 * sizeof(unsigned long long)));
     for (double& m : r->ms) m = 0.0;
     r->launches_tp = r->launches_tc = 0;
     return CL2_OK;

@@ -217,6 +217,10 @@ class Renderer:
     def set_counting(self, on=True):
         self._check(self._L.cl2_set_counting(self._h, int(bool(on))), "set_counting")
 
+    def set_levels_per_launch(self, levels):
+        """Bounces traced per launch (1..6); a pure performance knob, results are identical."""
+        self._check(self._L.cl2_set_levels_per_launch(self._h, int(levels)), "set_levels_per_launch")
+
     def set_debug_flags(self, flags):
         self._check(self._L.cl2_set_debug_flags(self._h, int(flags)), "set_debug_flags")
 

@@ -93,6 +93,11 @@ int cl2_gather_light_image(cl2_renderer* r);
 int cl2_process_images(cl2_renderer* r);
 int cl2_run_samples(cl2_renderer* r, int n);
 
+/* Subpath levels (bounces) traced per launch: 6 (default) walks a whole subpath in one launch with
+ * its state in registers; 1 compacts the survivors after every bounce (pays when most paths die
+ * early: open scenes).  Results are identical for every setting. */
+int cl2_set_levels_per_launch(cl2_renderer* r, int levels);
+
 /* -- accumulators: Renderer.summed_image / summed_sample_weights / summed_sample_counts /
  *    unidirectional_image_buffer (src/renderer.py:41-45).  Any pointer may be NULL. -- */
 int cl2_read_accumulators(cl2_renderer* r, float* summed_image /*H*W*3*/, float* summed_sample_weights /*H*W*/,

@@ -138,3 +138,18 @@ def test_multi_sample_accumulation(scene_name, request, oracle_mod):
     l2 = np.sqrt(((r.radiance - o.radiance) ** 2).sum(axis=2))
     assert l2.max() < 1e-3
     assert r.counters()["rays"] == o.rays_traced
+
+
+@pytest.mark.parametrize("levels", [1, 2, 3, 4])
+def test_levels_per_launch_is_a_pure_performance_knob(levels, glass_scene, oracle_mod):
+    """Subpaths traced 1/2/3/4 bounces per launch (queue compaction in between) == one launch == oracle."""
+    from clive2_amd import struct_types as st
+    r, o = _pair(glass_scene, oracle_mod)
+    r.set_levels_per_launch(levels)
+    _run_to_paths(r, o)
+    for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
+        assert r.export_paths(which).tobytes() == ref.tobytes()
+    assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
+    assert r.counters()["rays"] == o.rays_traced
+    with pytest.raises(Exception):
+        r.set_levels_per_launch(0)
