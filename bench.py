@@ -78,10 +78,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # Rehearsal knobs (NOT used by the driver): CLIVE2_BENCH_BACKEND=gloo reduces through the host and
+    # CLIVE2_BENCH_SHARE_GPU=1 puts every rank on cuda:0, so the N>1 code path can be exercised on a
+    # one-GPU box.  The measured configuration is nccl (= RCCL over xGMI), one rank per GPU.
+    backend = os.environ.get("CLIVE2_BENCH_BACKEND", "nccl")
+    if os.environ.get("CLIVE2_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import numpy as np
     import clive2_amd as c2
@@ -106,6 +115,7 @@ def main():
     n_node = cw["box_tests"] / max(cw["counted_rays"], 1)
     n_tri = cw["tri_tests"] / max(cw["counted_rays"], 1)
     r.set_counting(False)
+    r.reduce_accumulators()          # untimed: creates the RCCL communicator and its buffers before the clock starts
     r.reset_counters()
     r.reset_accumulators()
     r.set_profiling(True)
@@ -122,7 +132,7 @@ def main():
     c = r.counters()
     rays_local = c["rays"]
     if world > 1:
-        t = torch.tensor([float(rays_local), dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([float(rays_local), dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -153,7 +163,7 @@ def main():
             "config": {"workload": f"Cornell box (scene preset 'empty', 16 tris / 5 boxes) {W}x{H}, BDPT diffuse-only, "
                                    f"{args.steps} spp per GPU", "width": W, "height": H,
                        "rays_per_pixel_sample": round(rays_local / (args.steps * W * H), 3),
-                       "parallelism": f"sample-split x{world}, one RCCL all-reduce of the accumulators"},
+                       "parallelism": f"sample-split x{world}, one {'RCCL' if backend == 'nccl' else backend} all-reduce of the accumulators"},
             "roofline": {"bound": "hbm", "kernel": k_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "bytes_per_ray": round(b_ray, 1), "n_node": round(n_node, 3), "n_tri": round(n_tri, 3),

@@ -1,0 +1,135 @@
+"""Full-size (BASELINE.json configs) GPU checks: one exact oracle comparison at 1080p, then
+size-independent properties -- linearity of the accumulators, determinism, the BDPT-vs-unidirectional
+cross-estimator, ray-count bounds -- and the mesh configs (rough-glass sphere, ~82k-triangle blob)
+against the oracle at sizes it finishes in seconds."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LIGHT, CAMERA = 0, 1
+
+
+@pytest.fixture(scope="module")
+def cornell_1080p():
+    import clive2_amd as c2
+    return c2.create_scene_from_preset("empty", 1920, 1080)
+
+
+def test_1080p_one_sample_matches_oracle(cornell_1080p, oracle_mod):
+    """BASELINE config 2 geometry, one full sample: RNG state and filter aggregators bit-exact,
+    radiance within the north-star bound (per-pixel L2 < 1e-3; measured ~1e-7)."""
+    from clive2_amd.renderer import Renderer, make_seeds
+    B = 1920 * 1080
+    seeds = make_seeds(B)
+    r, o = Renderer(cornell_1080p, seeds=seeds), oracle_mod.OracleRenderer(cornell_1080p, seeds=seeds)
+    r.run_samples(1)
+    o.run_sample()
+    assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
+    agg = r.export_aggregators()
+    assert agg["total_contribution"].tobytes() == o.weight_aggregators["total_contribution"].tobytes()
+    assert agg["weights"].tobytes() == o.weight_aggregators["weights"].tobytes()
+    assert r.counters()["rays"] == o.rays_traced
+    l2 = np.sqrt(((r.radiance - o.radiance) ** 2).sum(axis=2))
+    assert l2.max() < 1e-3 and l2.max() < 1e-5
+    img, wts, cnt, uni = r.read_accumulators()
+    np.testing.assert_allclose(img, o.summed_image, rtol=5e-5, atol=1e-8)
+    assert uni.tobytes() == o.unidirectional_image_buffer.tobytes()
+
+
+def test_1080p_accumulators_are_linear_and_deterministic(cornell_1080p):
+    from clive2_amd.renderer import Renderer, make_seeds
+    seeds = make_seeds(1920 * 1080, rank=3)
+    a = Renderer(cornell_1080p, seeds=seeds)
+    a.run_samples(1)
+    i1, w1, c1, u1 = a.read_accumulators()
+    a.run_samples(1)
+    i2, w2, c2_, u2 = a.read_accumulators()
+    b = Renderer(cornell_1080p, seeds=seeds)
+    b.run_samples(2)
+    j2, x2, d2, v2 = b.read_accumulators()
+    assert np.array_equal(a.get_random_buffer(), b.get_random_buffer())
+    assert (c1 == 1).all() and (c2_ == 2).all() and (d2 == 2).all()
+    assert u2.tobytes() == v2.tobytes()                              # no atomics on this path: exact
+    np.testing.assert_allclose(i2, j2, rtol=2e-5, atol=1e-9)         # light splat order may differ
+    np.testing.assert_allclose(w2, x2, rtol=2e-5, atol=1e-9)
+    assert np.isfinite(i2).all() and (i2 >= 0).all() and (w2 > 0).mean() > 0.999
+    assert ((i2 - i1) >= -1e-6).all()                                # a sample only adds energy
+    c = b.counters()
+    per = c["rays"] / (2 * 1920 * 1080)
+    assert 36 < per < 45 and c["conn_rays"] < c["rays"]              # <= 48 by construction
+    # the reference's cross-check at full size: un-normalised BDPT sum vs unidirectional mean.  The
+    # two agree within 10 % at 48x48 (tests/test_oracle_pinning.py) but drift apart with resolution:
+    # the reference splats t=1 contributions without a pixel-count factor (quirk Q17), so
+    # only the order of magnitude is a size-independent property.
+    bd, un = (j2 / 2).mean(axis=(0, 1)), (v2 / 2).mean(axis=(0, 1))
+    assert np.all((bd / un > 0.5) & (bd / un < 1.5))
+
+
+def _glass(subdiv, w, h, alpha=0.1):
+    import clive2_amd as c2
+    from clive2_amd.load import get_materials
+    from clive2_amd.meshes import icosphere
+    mats = get_materials()
+    mats["alpha"][5] = alpha
+    v, f = icosphere(subdiv, radius=2.0, center=(0.0, 1.0, 0.0))
+    return c2.create_scene(w, h, np.array([0, 1.5, 6]), np.array([0, 0, -1]),
+                           file_specs=[dict(mesh=(v, f), material=5)], materials=mats)
+
+
+def test_config3_glass_sphere_vs_oracle(oracle_mod):
+    """BASELINE config 3 geometry (Cornell + 5,120-triangle rough-glass sphere, GGX alpha 0.1 +
+    transmission) at 160x90, 2 samples: subpaths bit-exact, image within tolerance."""
+    from clive2_amd.renderer import Renderer, make_seeds
+    scene = _glass(4, 160, 90)
+    assert len(scene.triangles) == 16 + 5120 and len(scene.boxes) > 256      # deeper than the LDS-staged top
+    seeds = make_seeds(160 * 90)
+    r, o = Renderer(scene, seeds=seeds), oracle_mod.OracleRenderer(scene, seeds=seeds)
+    for x in (r, o):
+        x.make_light_rays(); x.make_camera_rays(); x.trace_light_rays(); x.trace_camera_rays()
+    for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
+        assert r.export_paths(which).tobytes() == ref.tobytes()
+    mats_hit = o.out_camera_paths["rays"]["material"][o.out_camera_paths["length"] > 1, 1]
+    assert (mats_hit == 5).sum() > 500                                        # the sphere is actually hit
+    for x in (r, o):
+        x.join_paths(); x.finalize_samples(); x.gather_light_image(); x.process_images()
+    assert r.export_aggregators()["total_contribution"].tobytes() == o.weight_aggregators["total_contribution"].tobytes()
+    r.run_samples(1); o.run_sample()
+    np.testing.assert_allclose(r.read_accumulators()[0], o.summed_image, rtol=5e-5, atol=1e-8)
+    assert r.counters()["rays"] == o.rays_traced
+
+
+def test_config3_1080p_properties():
+    from clive2_amd.renderer import Renderer
+    scene = _glass(4, 1920, 1080)
+    r = Renderer(scene)
+    r.set_counting(True)
+    r.run_samples(2)
+    img, wts, cnt, uni = r.read_accumulators()
+    c = r.counters()
+    assert np.isfinite(img).all() and (cnt == 2).all() and img.mean() > 0
+    assert 20 < c["rays"] / (2 * 1920 * 1080) < 48
+    assert c["box_tests"] / c["counted_rays"] > 8           # a real tree walk, not the 5-node box
+
+
+def test_config4_blob_mesh_vs_oracle(oracle_mod):
+    """BASELINE config 4 stand-in: noisy icosphere, subdivision 5 = 20,480 triangles here
+    (81,920 at subdivision 6 in the bench), smooth normals, material 5 rough glass."""
+    import clive2_amd as c2
+    from clive2_amd.load import get_materials
+    from clive2_amd.meshes import noisy_blob
+    from clive2_amd.renderer import Renderer, make_seeds
+    mats = get_materials()
+    mats["alpha"][5] = 0.1
+    v, f = noisy_blob(subdiv=5)
+    scene = c2.create_scene(128, 72, np.array([0, 1.5, 6]), np.array([0, 0, -1]),
+                            file_specs=[dict(mesh=(v, f), material=5)], materials=mats)
+    seeds = make_seeds(128 * 72)
+    r, o = Renderer(scene, seeds=seeds), oracle_mod.OracleRenderer(scene, seeds=seeds)
+    r.run_samples(2)
+    o.run_sample(); o.run_sample()
+    assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
+    assert r.counters()["rays"] == o.rays_traced
+    np.testing.assert_allclose(r.read_accumulators()[0], o.summed_image, rtol=5e-5, atol=1e-8)
+    l2 = np.sqrt(((r.radiance - o.radiance) ** 2).sum(axis=2))
+    assert l2.max() < 1e-3
