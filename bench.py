@@ -51,6 +51,28 @@ def cpu_baseline(width, height, samples):
                       f"({o.rays_traced} rays, {dt:.1f} s; C oracle, OpenMP)"}
 
 
+def build_scene(name, W, H):
+    import numpy as np
+    import clive2_amd as c2
+    if name == "cornell":
+        return c2.create_scene_from_preset("empty", W, H), "Cornell box (scene preset 'empty', 16 tris / 5 boxes)"
+    from clive2_amd.load import get_materials
+    from clive2_amd import meshes
+    mats = get_materials()
+    mats["alpha"][5] = 0.1                       # rough glass (the shipped table has alpha 0)
+    if name == "glass":
+        specs = [dict(mesh=meshes.icosphere(4, radius=2.0, center=(0.0, 1.0, 0.0)), material=5)]
+        desc = "Cornell box + 5,120-tri rough-glass icosphere (config 3 stand-in)"
+    elif name == "blob":
+        specs = [dict(mesh=meshes.noisy_blob(subdiv=6), material=5)]
+        desc = "Cornell box + 81,920-tri noisy blob (config 4 stand-in)"
+    else:
+        specs = [dict(mesh=(v, f), material=m) for v, f, m in meshes.interior_grid()]
+        desc = "Cornell box + 49 x 20,480-tri icospheres (config 5 stand-in)"
+    s = c2.create_scene(W, H, np.array([0, 1.5, 6]), np.array([0, 0, -1]), file_specs=specs, materials=mats)
+    return s, desc + f", {len(s.triangles)} tris / {len(s.boxes)} boxes"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,6 +82,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-flags", type=int, default=0, help="performance experiments only (invalid renders)")
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "glass", "blob", "interior"],
+                    help="cornell = the BASELINE metric's workload (default); the others are the mesh configs "
+                         "(SURVEY 8d C3-C5 stand-ins), for profiling only")
     ap.add_argument("--levels-per-launch", type=int, default=6, help="subpath bounces per launch (1..6)")
     ap.add_argument("--cpu-width", type=int, default=1920)
     ap.add_argument("--cpu-height", type=int, default=1080)
@@ -97,7 +122,7 @@ def main():
     from clive2_amd.renderer import Renderer, make_seeds
 
     W, H = args.width, args.height
-    scene = c2.create_scene_from_preset("empty", W, H)
+    scene, scene_desc = build_scene(args.scene, W, H)
     r = Renderer(scene, seeds=make_seeds(W * H, rank=rank), device=local_rank)
 
     def barrier():
@@ -160,7 +185,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Cornell box (scene preset 'empty', 16 tris / 5 boxes) {W}x{H}, BDPT diffuse-only, "
+            "config": {"workload": f"{scene_desc} {W}x{H}, BDPT{' diffuse-only' if args.scene == 'cornell' else ''}, "
                                    f"{args.steps} spp per GPU", "width": W, "height": H,
                        "rays_per_pixel_sample": round(rays_local / (args.steps * W * H), 3),
                        "parallelism": f"sample-split x{world}, one {'RCCL' if backend == 'nccl' else backend} all-reduce of the accumulators"},

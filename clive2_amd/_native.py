@@ -16,8 +16,11 @@ _SOURCES = [os.path.join(_PKG, "csrc", n) for n in
 _HEADER = os.path.join(os.path.dirname(_PKG), "include", "clive2_amd.h")
 
 # -ffp-contract=off / no fast-math: every float op of the kernels rounds once, in source order.
+# -fno-slp-vectorize: packed fp32 VALU ops (v_pk_mul/add_f32) issue at half the rate of scalar ones on
+# gfx950 (tools/valu_rate.hip: 4.4 vs 2.3 cycles per wave-instruction), so SLP packing only adds the
+# register shuffles that feed them.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-               "-fPIC", "-shared"]
+               "-fno-slp-vectorize", "-fPIC", "-shared"]
 
 
 class RendererError(RuntimeError):
