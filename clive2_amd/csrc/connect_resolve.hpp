@@ -21,11 +21,16 @@
 
 namespace cl2 {
 
-struct LightVtx {
-    V3 o, n, col;
+struct LightVtx {          // the part of a light vertex every pair touches: registers
+    V3 o;
     float c, l, tot, cosv;
     int tri, meta;
 };
+// Normal and colour of the light vertices are read once per contributing pair only: they live in LDS
+// ([word][thread], conflict-free) so the kernel fits 3 waves per SIMD instead of 2.
+__device__ __forceinline__ V3 lds_v3(const float* base, int v) {
+    return v3(base[(3 * v + 0) * BLOCK + threadIdx.x], base[(3 * v + 1) * BLOCK + threadIdx.x], base[(3 * v + 2) * BLOCK + threadIdx.x]);
+}
 
 // One strategy pair with s = S (compile time).  Returns true when a contribution was produced.
 template <int S>
@@ -34,7 +39,7 @@ __device__ __forceinline__ void resolve_pair(
         unsigned l_spec, unsigned c_spec, bool spec7,
         // camera junction vertex t-1 and per-path camera tables (LDS)
         V3 c_o_in, V3 c_n_in, float c_c, float c_l, float c_tot_in, float c_cos_in, int c_tri, int c_meta,
-        V3 prior_camera_color, const float* GCs, const float* RCs /* [m*BLOCK + tid] */,
+        V3 prior_camera_color, const float* GCs, const float* RCs /* [m*BLOCK + tid] */, const float* LNs, const float* LCs,
         unsigned long long mask, float2 h, const float4* __restrict__ tri_shade,
         const MaterialDev* __restrict__ mats, const CameraRec& cam, V3 focal, V3 cam_dir,
         V3& total, float& contrib_weight_sum, float4* __restrict__ light_image, int debug_flags) {
@@ -136,9 +141,9 @@ __device__ __forceinline__ void resolve_pair(
         contrib_weight_sum += w;
     } else if (t == 1) {                                                      // :787-793, :817-823, K8 :952-961
         const LightVtx& a = lv[S - 1];
-        const V3 prior_color = lv[(S - 2) > 0 ? (S - 2) : 0].col;
+        const V3 prior_color = lds_v3(LCs, (S - 2) > 0 ? (S - 2) : 0);
         float new_light_f = 1.0f;
-        if (S > 1) new_light_f = __builtin_fabsf(dot(dir_l_to_c, a.n)) / PI_F;
+        if (S > 1) new_light_f = __builtin_fabsf(dot(dir_l_to_c, lds_v3(LNs, S - 1))) / PI_F;
         const V3 mcol = v3(mats[a.meta & 0xFF].color_type);
         const float shade = new_light_f * Gj / p_s;
         if (light_pixel_idx >= 0 && light_pixel_idx < B && !(debug_flags & 1)) {
@@ -157,8 +162,8 @@ __device__ __forceinline__ void resolve_pair(
         V3 light_color;
         if (S == 1) light_color = v3(mats[a.meta & 0xFF].emission_alpha);
         else {
-            const V3 prior_light_color = lv[S >= 2 ? S - 2 : 0].col;
-            const float new_light_f = __builtin_fabsf(dot(dir_l_to_c, a.n)) / PI_F;
+            const V3 prior_light_color = lds_v3(LCs, S >= 2 ? S - 2 : 0);
+            const float new_light_f = __builtin_fabsf(dot(dir_l_to_c, lds_v3(LNs, S - 1))) / PI_F;
             light_color = (prior_light_color * new_light_f) * v3(mats[a.meta & 0xFF].color_type);
         }
         const V3 color = camera_color * light_color;
@@ -175,6 +180,8 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
         float4* __restrict__ uni_out, Stats* stats, int debug_flags) {
     __shared__ float GCs[(MAX_VERTS - 1) * BLOCK];     // GC[v] = G(camera[v], camera[v+1])
     __shared__ float RCs[(MAX_VERTS - 1) * BLOCK];     // RC[m]: ratio of camera vertex m with both neighbours on the camera side
+    __shared__ float LNs[3 * MAX_VERTS * BLOCK];       // light vertex normals
+    __shared__ float LCs[3 * MAX_VERTS * BLOCK];       // light vertex colours (throughput numerators)
     const int tid = threadIdx.x;
     const int pid = blockIdx.x * BLOCK + tid;
     if (pid >= B) return;                              // no block-wide barrier below: LDS rows are private per thread
@@ -183,18 +190,55 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
     const V3 focal = cam3(cam.focal_point), cam_dir = cam3(cam.direction);
     const bool spec7 = __float_as_int(mats[7].color_type.w) > 0;
 
+    // ---- camera subpath: per-path tables to LDS.  All loads are issued before the first use (one
+    // memory round trip instead of one per vertex); done first so the registers are free again
+    // before the light subpath moves in. ----
+    unsigned c_spec = 0;
+    int first_light_hit = 0;                         // first camera vertex v >= 1 with hit_light (0 = none)
+    {
+        float4 ca[MAX_VERTS], cb[MAX_VERTS], cc[MAX_VERTS];
+#pragma unroll
+        for (int v = 0; v < MAX_VERTS; v++) {
+            const size_t k = (size_t)(v < Lc ? v : 0) * B + pid;      // clamp: always a valid address
+            ca[v] = cp.P0[k]; cb[v] = cp.P1[k]; cc[v] = cp.P2[k];
+        }
+        V3 prev_o = v3(0, 0, 0);
+        float prev_cos = 0.0f, prev_l = 0.0f, prev_c = 0.0f, prev_G = 0.0f;
+#pragma unroll
+        for (int v = 0; v < MAX_VERTS; v++) {
+            if (v < Lc) {
+                const float4 a = ca[v], b = cb[v], c = cc[v];
+                const float cosv = __builtin_fabsf(dot(v3(b), v3(c)));
+                const int meta = __float_as_int(c.w);
+                if (__float_as_int(mats[meta & 0xFF].color_type.w) > 0) c_spec |= 1u << v;
+                if (v > 0 && first_light_hit == 0 && (meta & META_HIT_LIGHT)) first_light_hit = v;
+                if (v > 0) {
+                    const float G = geom_term(prev_cos, cosv, prev_o, v3(a));          // GC[v-1]
+                    GCs[(v - 1) * BLOCK + tid] = G;
+                    // ratio of camera vertex m = v-1 once its far neighbour (v) is known
+                    const int m = v - 1;
+                    RCs[m * BLOCK + tid] = (m == 0) ? (prev_l * G) / prev_c : (prev_l * G) / (prev_c * prev_G);
+                    prev_G = G;
+                }
+                prev_o = v3(a); prev_cos = cosv; prev_l = b.w; prev_c = a.w;
+            }
+        }
+    }
+
     // ---- light subpath -> registers; adjacent geometry terms and interior ratios ----
     LightVtx lv[MAX_VERTS];
     float GL[MAX_VERTS], RL[MAX_VERTS];
     unsigned l_spec = 0;
 #pragma unroll
     for (int v = 0; v < MAX_VERTS; v++) {
-        lv[v] = LightVtx{v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), 0.0f, 0.0f, 0.0f, 0.0f, -1, 0};
+        lv[v] = LightVtx{v3(0, 0, 0), 0.0f, 0.0f, 0.0f, 0.0f, -1, 0};
         GL[v] = 0.0f; RL[v] = 0.0f;
         if (v < Ll) {
             const size_t k = (size_t)v * B + pid;
             const float4 a = lp.P0[k], b = lp.P1[k], c = lp.P2[k], d = lp.P3[k];
-            lv[v].o = v3(a); lv[v].n = v3(c); lv[v].col = v3(d);
+            lv[v].o = v3(a);
+            LNs[(3 * v + 0) * BLOCK + tid] = c.x; LNs[(3 * v + 1) * BLOCK + tid] = c.y; LNs[(3 * v + 2) * BLOCK + tid] = c.z;
+            LCs[(3 * v + 0) * BLOCK + tid] = d.x; LCs[(3 * v + 1) * BLOCK + tid] = d.y; LCs[(3 * v + 2) * BLOCK + tid] = d.z;
             lv[v].c = a.w; lv[v].l = b.w; lv[v].tot = d.w;
             lv[v].cosv = __builtin_fabsf(dot(v3(b), v3(c)));
             lv[v].tri = lp.tri[k];
@@ -213,30 +257,9 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
         }
     }
 
-    // ---- camera subpath: per-path tables to LDS ----
-    unsigned c_spec = 0;
-    {
-        V3 prev_o = v3(0, 0, 0);
-        float prev_cos = 0.0f, prev_l = 0.0f, prev_c = 0.0f, prev_G = 0.0f;
-        for (int v = 0; v < Lc; v++) {
-            const size_t k = (size_t)v * B + pid;
-            const float4 a = cp.P0[k], b = cp.P1[k], c = cp.P2[k];
-            const float cosv = __builtin_fabsf(dot(v3(b), v3(c)));
-            if (__float_as_int(mats[__float_as_int(c.w) & 0xFF].color_type.w) > 0) c_spec |= 1u << v;
-            if (v > 0) {
-                const float G = geom_term(prev_cos, cosv, prev_o, v3(a));          // GC[v-1]
-                GCs[(v - 1) * BLOCK + tid] = G;
-                // ratio of camera vertex m = v-1 once its far neighbour (v) is known
-                const int m = v - 1;
-                RCs[m * BLOCK + tid] = (m == 0) ? (prev_l * G) / prev_c : (prev_l * G) / (prev_c * prev_G);
-                prev_G = G;
-            }
-            prev_o = v3(a); prev_cos = cosv; prev_l = b.w; prev_c = a.w;
-        }
-    }
-
     V3 total = v3(0, 0, 0);
     float contrib_weight_sum = 0.0f;
+    float4 uni = make_float4(0, 0, 0, 0);
 
     for (int t = 1; t < Lc + 1; t++) {
         const size_t ck = (size_t)(t - 1) * B + pid;
@@ -247,6 +270,12 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
         const float c_cos = __builtin_fabsf(dot(v3(cP1), c_n));
         V3 prior_camera_color = v3(0, 0, 0);
         if (t >= 2) prior_camera_color = v3(cp.P3[ck - B]);
+        // unidirectional estimate of generate_paths (camera pass), trace.metal:523-528: first stored
+        // vertex v with hit_light -> rays[v-1].color / rays[v].tot_importance; both are this iteration's loads
+        if (t - 1 == first_light_hit && first_light_hit > 0) {
+            const V3 c = prior_camera_color / cP3.w;
+            uni = make_float4(c.x, c.y, c.z, 1.0f);
+        }
         // all closest-hit results of this t in flight at once (entries of culled pairs are never used)
         float2 hits[MAX_VERTS + 1];
         hits[0] = make_float2(0.0f, 0.0f);
@@ -255,7 +284,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
 #define CL2_PAIR(S)                                                                                             \
         if ((S) <= Ll && t + (S) >= 2)                                                                          \
             resolve_pair<S>(t, B, pid, lv, GL, RL, l_spec, c_spec, spec7, c_o, c_n, cP0.w, cP1.w, cP3.w, c_cos, \
-                            c_tri, c_meta, prior_camera_color, GCs, RCs, mask, hits[S], tri_shade, mats, cam,  \
+                            c_tri, c_meta, prior_camera_color, GCs, RCs, LNs, LCs, mask, hits[S], tri_shade, mats, cam, \
                             focal, cam_dir, total, contrib_weight_sum, light_image, debug_flags)
         CL2_PAIR(0); CL2_PAIR(1); CL2_PAIR(2); CL2_PAIR(3); CL2_PAIR(4); CL2_PAIR(5); CL2_PAIR(6);
 #undef CL2_PAIR
@@ -294,16 +323,6 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
     agg[(size_t)11 * B + pid] = total.z;
     agg[(size_t)12 * B + pid] = contrib_weight_sum;
 
-    // ---- unidirectional estimate of generate_paths (camera pass), trace.metal:523-528 ----
-    float4 uni = make_float4(0, 0, 0, 0);
-    for (int v = 1; v < Lc; v++) {
-        const size_t kk = (size_t)v * B + pid;
-        if (__float_as_int(cp.P2[kk].w) & META_HIT_LIGHT) {
-            const V3 c = v3(cp.P3[kk - B]) / cp.P3[kk].w;
-            uni = make_float4(c.x, c.y, c.z, 1.0f);
-            break;
-        }
-    }
     uni_out[pid] = uni;
 }
 

@@ -210,7 +210,7 @@ int launch_join(cl2_renderer* r) {
                            r->pb[CL2_CAMERA], r->d_mats, r->d_tri_shade, r->cam, r->d_cmask, r->d_chit, r->d_agg,               \
                            r->d_light_image, r->d_uni, r->d_stats, r->debug_flags)
         const int occ = (r->debug_flags >> 4) & 7;      // experiment switch: register budget of the resolve kernel
-        if (occ == 3) CL2_RESOLVE(3); else if (occ == 4) CL2_RESOLVE(4); else CL2_RESOLVE(2);
+        if (occ == 2) CL2_RESOLVE(2); else if (occ == 4) CL2_RESOLVE(4); else CL2_RESOLVE(3);
 #undef CL2_RESOLVE
     }
     HIP_TRY(r, hipGetLastError());
