@@ -12,7 +12,8 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libclive2_amd.so")
 _SOURCES = [os.path.join(_PKG, "csrc", n) for n in
-            ("renderer_api.hip", "kernels.hpp", "bvh_traverse.hpp", "bsdf.hpp", "vecmath.hpp", "detmath.hpp")]
+            ("renderer_api.hip", "kernels.hpp", "connect_resolve.hpp", "bvh_traverse.hpp", "bvh_builder.hpp", "bsdf.hpp",
+             "vecmath.hpp", "detmath.hpp")]
 _HEADER = os.path.join(os.path.dirname(_PKG), "include", "clive2_amd.h")
 
 # -ffp-contract=off / no fast-math: every float op of the kernels rounds once, in source order.
@@ -39,7 +40,7 @@ class Counters(C.Structure):
 
 
 EXPORTS = [
-    "cl2_create", "cl2_destroy", "cl2_last_error", "cl2_abi_version", "cl2_upload_scene", "cl2_set_seeds",
+    "cl2_create", "cl2_destroy", "cl2_last_error", "cl2_abi_version", "cl2_build_bvh", "cl2_upload_scene", "cl2_set_seeds",
     "cl2_get_seeds", "cl2_make_light_rays", "cl2_make_camera_rays", "cl2_trace_light_rays",
     "cl2_trace_camera_rays", "cl2_join_paths", "cl2_finalize_samples", "cl2_gather_light_image",
     "cl2_process_images", "cl2_run_samples", "cl2_set_levels_per_launch", "cl2_read_accumulators", "cl2_reset_accumulators",

@@ -115,10 +115,47 @@ class _Tree:
         return l, r
 
 
-def construct_BVH(root_box):
+NATIVE_THRESHOLD = 4096      # above this many triangles "auto" uses the native O(n log n) builder
+
+
+class _FlatTree:
+    """Result of the native builder: already flattened (Box[], leaf-ordered permutation)."""
+
+    def __init__(self, soup, boxes, perm, max_pending):
+        self.soup, self.boxes, self.perm, self.max_pending = soup, boxes, perm, max_pending
+        self.members = [None] * len(boxes)       # count_boxes() compatibility
+
+
+def _construct_native(root_box):
+    import ctypes as C
+    from . import _native
+    L = _native.lib()
+    n = len(root_box)
+    tmin = np.ascontiguousarray(root_box.mins, dtype=np.float64)
+    tmax = np.ascontiguousarray(root_box.maxes, dtype=np.float64)
+    boxes = np.zeros(2 * n, dtype=struct_types.Box)
+    perm = np.zeros(n, dtype=np.int64)
+    n_boxes = C.c_int64(0)
+    L.cl2_build_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                C.POINTER(C.c_int64), C.c_void_p]
+    rc = L.cl2_build_bvh(_native.ptr(tmin), _native.ptr(tmax), n, MAX_MEMBERS, MAX_DEPTH, _native.ptr(boxes),
+                         len(boxes), C.byref(n_boxes), _native.ptr(perm))
+    if rc != 0:
+        raise _native.RendererError(f"cl2_build_bvh failed ({rc}): {L.cl2_last_error(None).decode()}")
+    root_box.tree = _FlatTree(root_box, boxes[:n_boxes.value].copy(), perm, 0)
+    return root_box
+
+
+def construct_BVH(root_box, builder="auto"):
     """Grow the tree in the reference's order: LIFO work list, right child pushed first,
     and a node becomes a leaf when it has <= MAX_MEMBERS triangles or when MORE than
-    MAX_DEPTH nodes are still pending (bvh.py:292-295).  Returns `root_box` with `.tree`."""
+    MAX_DEPTH nodes are still pending (bvh.py:292-295).  Returns `root_box` with `.tree`.
+
+    builder: "numpy" = this module's restatement (identical to the reference's tree, ties
+    included); "native" = the C++ builder in libclive2_amd.so (same rule, O(n log n), equal
+    centroids ordered by id); "auto" = native above NATIVE_THRESHOLD triangles."""
+    if builder == "native" or (builder == "auto" and len(root_box) > NATIVE_THRESHOLD):
+        return _construct_native(root_box)
     tree = _Tree(root_box)
     pending = [0]
     deepest = 0
@@ -142,6 +179,8 @@ def np_flatten_bvh(root):
     """Breadth-first numbering -> (Box[], Triangle[]) in the reference layout."""
     tree = root.tree if root.tree is not None else _Tree(root)
     soup = tree.soup
+    if isinstance(tree, _FlatTree):
+        return tree.boxes, _fill_triangles(soup, tree.perm)
     n_nodes = len(tree.members)
     boxes = np.zeros(n_nodes, dtype=struct_types.Box)
     bfs = [0]
@@ -164,7 +203,11 @@ def np_flatten_bvh(root):
     perm = np.concatenate(leaf_chunks) if leaf_chunks else np.zeros(0, dtype=np.int64)
     assert head == n_nodes and n_tri == len(soup) == len(perm)
 
-    tris = np.zeros(n_tri, dtype=struct_types.Triangle)
+    return boxes, _fill_triangles(soup, perm)
+
+
+def _fill_triangles(soup, perm):
+    tris = np.zeros(len(perm), dtype=struct_types.Triangle)
     for k, name in enumerate(("v0", "v1", "v2")):
         tris[name][:, :3] = soup.triangles[perm, k]
     for k, name in enumerate(("n0", "n1", "n2")):
@@ -173,4 +216,4 @@ def np_flatten_bvh(root):
     tris["material"] = soup.material[perm]
     tris["is_light"] = soup.emitter[perm]
     tris["is_camera"] = soup.camera[perm]
-    return boxes, tris
+    return tris

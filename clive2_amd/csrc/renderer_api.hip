@@ -15,6 +15,7 @@
 
 #include "../../include/clive2_amd.h"
 #include "kernels.hpp"
+#include "bvh_builder.hpp"
 
 using namespace cl2;
 
@@ -256,6 +257,28 @@ int need_scene(cl2_renderer* r) {
 extern "C" {
 
 int cl2_abi_version(void) { return 1; }
+
+int cl2_build_bvh(const double* tri_min, const double* tri_max, int64_t n_triangles, int max_members, int max_depth,
+                  void* out_boxes, int64_t box_capacity, int64_t* n_boxes_out, int64_t* out_perm) {
+    if (!tri_min || !tri_max || !out_boxes || !n_boxes_out || !out_perm || n_triangles < 1 || max_members < 1 ||
+        n_triangles > (int64_t)1 << 30) {
+        g_create_error = "cl2_build_bvh: bad argument";
+        return CL2_E_INVALID;
+    }
+    BvhBuildResult res;
+    try {
+        res = build_bvh_sah(tri_min, tri_max, n_triangles, max_members, max_depth);
+    } catch (const std::exception& ex) {
+        g_create_error = std::string("cl2_build_bvh: ") + ex.what();
+        return CL2_E_NOMEM;
+    }
+    if ((int64_t)res.boxes.size() > box_capacity) { g_create_error = "cl2_build_bvh: box_capacity too small"; return CL2_E_INVALID; }
+    static_assert(sizeof(HostBox) == 48, "Box record");
+    std::memcpy(out_boxes, res.boxes.data(), res.boxes.size() * sizeof(HostBox));
+    std::memcpy(out_perm, res.perm.data(), res.perm.size() * sizeof(int64_t));
+    *n_boxes_out = (int64_t)res.boxes.size();
+    return CL2_OK;
+}
 
 const char* cl2_last_error(const cl2_renderer* r) { return r ? r->err.c_str() : g_create_error.c_str(); }
 

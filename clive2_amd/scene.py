@@ -55,7 +55,7 @@ class Scene:
 
 
 def create_scene(pixel_width=1280, pixel_height=720, cam_center=ZERO_VECTOR, cam_direction=UNIT_Z,
-                 file_specs=None, materials=None, verbose=False):
+                 file_specs=None, materials=None, verbose=False, bvh_builder="auto"):
     camera = Camera(center=cam_center, direction=cam_direction, pixel_width=pixel_width,
                     pixel_height=pixel_height, phys_width=pixel_width / pixel_height, phys_height=1)
     soup = FastTreeBox.from_triangle_objects(camera_geometry(camera) + triangles_for_box())
@@ -74,7 +74,7 @@ def create_scene(pixel_width=1280, pixel_height=720, cam_center=ZERO_VECTOR, cam
             raise NotImplementedError(spec["file_path"])
 
     t0 = time.time()
-    boxes, tris = np_flatten_bvh(construct_BVH(soup))
+    boxes, tris = np_flatten_bvh(construct_BVH(soup, builder=bvh_builder))
     if verbose:
         print(f"BVH construction took {time.time() - t0:.4f} seconds")
 

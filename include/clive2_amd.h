@@ -65,6 +65,13 @@ void cl2_destroy(cl2_renderer* r);
 const char* cl2_last_error(const cl2_renderer* r);   /* r may be NULL: error of the last failed cl2_create */
 int cl2_abi_version(void);
 
+/* -- native host BVH builder: construct_BVH + np_flatten_bvh (src/bvh.py:288-313, :329-389) in one
+ *    call, O(n log n).  Inputs: per-triangle AABBs (float64, n x 3 each).  Outputs: Box records in the
+ *    reference's flattened convention (capacity >= 2n-1 is always enough) and the leaf-ordered triangle
+ *    permutation.  Needs no GPU.  On failure cl2_last_error(NULL) holds the message. -- */
+int cl2_build_bvh(const double* tri_min, const double* tri_max, int64_t n_triangles, int max_members, int max_depth,
+                  void* out_boxes, int64_t box_capacity, int64_t* n_boxes_out, int64_t* out_perm);
+
 /* -- scene upload: replaces the nine dev.buffer(...) uploads of create_scene
  *    (src/scene.py:74-89).  Arrays are in the reference layouts; light_* are the emitter
  *    triangle list, its areas and its indices into `triangles`. -- */
