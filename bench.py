@@ -86,6 +86,7 @@ def main():
                     help="cornell = the BASELINE metric's workload (default); the others are the mesh configs "
                          "(SURVEY 8d C3-C5 stand-ins), for profiling only")
     ap.add_argument("--levels-per-launch", type=int, default=6, help="subpath bounces per launch (1..6)")
+    ap.add_argument("--traversal-mode", type=int, default=0, help="0 auto, 1 fused, 2 persistent traversal with ray replacement")
     ap.add_argument("--cpu-width", type=int, default=1920)
     ap.add_argument("--cpu-height", type=int, default=1080)
     ap.add_argument("--cpu-samples", type=int, default=1)
@@ -132,6 +133,7 @@ def main():
         torch.cuda.synchronize()
 
     r.set_levels_per_launch(args.levels_per_launch)
+    r.set_traversal_mode(args.traversal_mode)
 
     # untimed: warm-up (also the counting pass that measures N_node / N_tri per ray)
     r.set_counting(True)

@@ -183,6 +183,57 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_paths(
     }
 }
 
+// ---------------------------------------------------------------- persistent traversal kernels (large scenes)
+struct PathRaySource {          // subpath rays: queue entry -> pixel -> (P0.xyz, P1.xyz) of one level
+    const int* queue; const float4* P0v; const float4* P1v; float4* hit;
+    __device__ __forceinline__ int pid(unsigned j) const { return queue ? queue[j] : (int)j; }
+    __device__ __forceinline__ void load(unsigned j, V3& o, V3& d) const { const int p = pid(j); o = v3(P0v[p]); d = v3(P1v[p]); }
+    __device__ __forceinline__ void store(unsigned j, const Hit& h) const {
+        hit[pid(j)] = make_float4(__int_as_float(h.tri), h.t, h.u, h.v);
+    }
+};
+
+struct ConnRaySource {          // connection rays: tag {slot, pixel} -> light vertex s-1 toward focal point / camera vertex t-1
+    const int* ctag; const float4* LP0; const float4* CP0; float2* chit; V3 focal; int B;
+    __device__ __forceinline__ void load(unsigned j, V3& o, V3& d) const {
+        const int tag = ctag[j];
+        const int pid = tag & ((1 << TAG_PID_BITS) - 1), slot = (unsigned)tag >> TAG_PID_BITS;
+        const int t = slot / 6 + 1, s = slot % 6 + 1;
+        o = v3(LP0[(size_t)(s - 1) * B + pid]);
+        V3 target = focal;
+        if (t > 1) target = v3(CP0[(size_t)(t - 1) * B + pid]);
+        d = normalize(target - o);
+    }
+    __device__ __forceinline__ void store(unsigned j, const Hit& h) const {
+        const int tag = ctag[j];
+        const int pid = tag & ((1 << TAG_PID_BITS) - 1), slot = (unsigned)tag >> TAG_PID_BITS;
+        chit[(size_t)slot * B + pid] = make_float2(__int_as_float(h.tri), h.t);
+    }
+};
+
+template <bool COUNT, class Source>
+__global__ __launch_bounds__(BLOCK) void k_traverse_persistent(BvhView bvh, const unsigned* __restrict__ count,
+                                                              unsigned* __restrict__ work_counter, Source src, Stats* stats,
+                                                              int is_conn) {
+    __shared__ BvhLds lds;
+    stage_bvh(lds, bvh);
+    const unsigned n = *count;
+    unsigned nb = 0, nt = 0;
+    traverse_persistent<COUNT>(lds, bvh, n, work_counter, src, nb, nt);
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) { nb += __shfl_down(nb, off); nt += __shfl_down(nt, off); }
+        if (lane_id() == 0) {
+            atomicAdd(&stats->box_tests, (unsigned long long)nb);
+            atomicAdd(&stats->tri_tests, (unsigned long long)nt);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&stats->rays, (unsigned long long)n);
+        if (is_conn) atomicAdd(&stats->conn_rays, (unsigned long long)n);
+        if (COUNT) atomicAdd(&stats->counted_rays, (unsigned long long)n);
+    }
+}
+
 // ---------------------------------------------------------------- K3: generate_paths, levels [first, end)
 // trace.metal:407-516 for the iterations first..end-1 of the path loop, one thread per queued path.
 //
@@ -201,18 +252,22 @@ struct ShadeLds {
     MaterialDev mats[LDS_MAT_CAP];
 };
 
-template <bool FROM_CAMERA, bool COUNT>
+template <bool FROM_CAMERA, bool COUNT, bool EXT_HIT>
 __global__ __launch_bounds__(BLOCK) void k_trace_subpath(
         BvhView bvh, Stats* stats, int first, int end, const int* __restrict__ queue_in,
         const unsigned* __restrict__ count_in, int* __restrict__ queue_out, unsigned* __restrict__ count_out, int B,
         PathBufs pb, uint2* __restrict__ seeds, const float4* __restrict__ tri_shade_g,
-        const MaterialDev* __restrict__ mats_g, int n_mats, unsigned long long* __restrict__ block_stats) {
+        const MaterialDev* __restrict__ mats_g, int n_mats, unsigned long long* __restrict__ block_stats,
+        const float4* __restrict__ ext_hit) {
+    // EXT_HIT: the closest hits of the (single) level were produced by k_traverse_persistent (large
+    // scenes: traversal with ray replacement runs as its own launch); the BVH is not staged here.
     __shared__ BvhLds lds;
     __shared__ ShadeLds sh;
     const bool shade_lds = bvh.lds_tris != 0, mats_lds = n_mats <= LDS_MAT_CAP;
     if (shade_lds) for (int i = threadIdx.x; i < 4 * bvh.n_tris; i += BLOCK) sh.tri_shade[i] = tri_shade_g[i];
     if (mats_lds) for (int i = threadIdx.x; i < n_mats; i += BLOCK) sh.mats[i] = mats_g[i];
-    stage_bvh(lds, bvh);                                   // ends with the barrier
+    if (!EXT_HIT) stage_bvh(lds, bvh);                     // ends with the barrier
+    else __syncthreads();
 
     const unsigned n = *count_in;
     const unsigned j = blockIdx.x * BLOCK + threadIdx.x;
@@ -243,8 +298,14 @@ __global__ __launch_bounds__(BLOCK) void k_trace_subpath(
         float n_tot = 0.0f, next_fwd = 0.0f;
         int n_meta = 0, n_tri = -1;
         if (alive) {
-            nrays++;
-            const Hit hh = closest_hit<COUNT>(lds, bvh, ro, rd, rcp3(rd), nb, nt);     // :409-415
+            Hit hh;
+            if (EXT_HIT) {
+                const float4 h4 = ext_hit[pid];
+                hh = Hit{__float_as_int(h4.x), h4.y, h4.z, h4.w};
+            } else {
+                nrays++;
+                hh = closest_hit<COUNT>(lds, bvh, ro, rd, rcp3(rd), nb, nt);             // :409-415
+            }
             const int best_i = hh.tri;
             if (best_i != -1) {
                 const float best_t = hh.t, u = hh.u, v = hh.v;

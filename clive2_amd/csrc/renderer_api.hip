@@ -45,6 +45,8 @@ struct cl2_renderer {
     std::string err;
     bool scene_ok = false, profiling = false, counting = false;
     int debug_flags = 0;
+    int traversal_mode = 0;              // 0 auto, 1 fused (one ray per lane), 2 split (persistent traversal + ray replacement)
+    unsigned* d_work = nullptr;          // [8] work counters of the persistent traversal launches
     int levels_per_launch = MAX_VERTS;   // subpath levels per launch (6 = one launch, 1 = compaction after every bounce)
 
     // scene
@@ -157,11 +159,21 @@ int launch_generate(cl2_renderer* r, int which) {
     return CL2_OK;
 }
 
+// Large scenes (tree not LDS-resident): traversal runs as its own persistent launch with lane-level
+// ray replacement, one bounce launch per level consumes its hits.
+inline bool split_mode(const cl2_renderer* r) {
+    const bool all_lds = r->bvh.lds_tris && r->bvh.n_nodes <= r->bvh.n_lds_nodes;
+    return r->traversal_mode == 2 || (r->traversal_mode == 0 && !all_lds);
+}
+inline int persistent_grid() { return 256 * 8; }      // 256 CUs x 8 workgroups of 4 waves = 32 waves per CU
+
 int launch_trace(cl2_renderer* r, int which) {
     const int B = r->B;
     PathBufs pb = r->pb[which];
     HIP_TRY(r, hipMemsetAsync(r->d_qcount + 1, 0, 6 * sizeof(unsigned), r->stream));
-    const int step = std::max(1, std::min(r->levels_per_launch, (int)MAX_VERTS));
+    const bool split = split_mode(r);
+    if (split) HIP_TRY(r, hipMemsetAsync(r->d_work, 0, 8 * sizeof(unsigned), r->stream));
+    const int step = split ? 1 : std::max(1, std::min(r->levels_per_launch, (int)MAX_VERTS));
     for (int first = 0; first < MAX_VERTS; first += step) {
         const int end = std::min(first + step, (int)MAX_VERTS);
         // queue slot k holds the paths alive after level k-1 (slot 0 = everybody, count B)
@@ -169,14 +181,28 @@ int launch_trace(cl2_renderer* r, int which) {
         const unsigned* c_in = r->d_qcount + first;
         int* q_out = r->d_queue + (size_t)(end - 1) * B;
         unsigned* c_out = r->d_qcount + end;
-        Timed t(r, ST_TRAVERSE_PATHS);
-#define CL2_TRACE(CAM, CNT)                                                                                              \
-        hipLaunchKernelGGL((k_trace_subpath<CAM, CNT>), dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, r->bvh, r->d_stats, first, \
-                           end, q_in, c_in, q_out, c_out, B, pb, r->d_seeds, r->d_tri_shade, r->d_mats, r->n_mats, r->d_block_stats)
-        if (which == CL2_CAMERA) { if (r->counting) CL2_TRACE(true, true); else CL2_TRACE(true, false); }
-        else { if (r->counting) CL2_TRACE(false, true); else CL2_TRACE(false, false); }
+        if (split) {
+            Timed t(r, ST_TRAVERSE_PATHS);
+            PathRaySource src{q_in, pb.P0 + (size_t)first * B, pb.P1 + (size_t)first * B, r->d_hit};
+            if (r->counting)
+                hipLaunchKernelGGL((k_traverse_persistent<true, PathRaySource>), dim3(persistent_grid()), dim3(BLOCK), 0, r->stream,
+                                   r->bvh, c_in, r->d_work + first, src, r->d_stats, 0);
+            else
+                hipLaunchKernelGGL((k_traverse_persistent<false, PathRaySource>), dim3(persistent_grid()), dim3(BLOCK), 0, r->stream,
+                                   r->bvh, c_in, r->d_work + first, src, r->d_stats, 0);
+            r->launches_tp++;
+            HIP_TRY(r, hipGetLastError());
+        }
+        Timed t(r, split ? ST_BOUNCE : ST_TRAVERSE_PATHS);
+#define CL2_TRACE(CAM, CNT, EXT)                                                                                          \
+        hipLaunchKernelGGL((k_trace_subpath<CAM, CNT, EXT>), dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, r->bvh, r->d_stats,  \
+                           first, end, q_in, c_in, q_out, c_out, B, pb, r->d_seeds, r->d_tri_shade, r->d_mats, r->n_mats,        \
+                           r->d_block_stats, r->d_hit)
+        if (split) { if (which == CL2_CAMERA) CL2_TRACE(true, false, true); else CL2_TRACE(false, false, true); }
+        else if (which == CL2_CAMERA) { if (r->counting) CL2_TRACE(true, true, false); else CL2_TRACE(true, false, false); }
+        else { if (r->counting) CL2_TRACE(false, true, false); else CL2_TRACE(false, false, false); }
 #undef CL2_TRACE
-        r->launches_tp++;
+        if (!split) r->launches_tp++;
         HIP_TRY(r, hipGetLastError());
     }
     return CL2_OK;
@@ -193,6 +219,17 @@ int launch_join(cl2_renderer* r) {
     HIP_TRY(r, hipGetLastError());
     {
         Timed t(r, ST_TRAVERSE_CONN);
+        if (split_mode(r)) {
+            HIP_TRY(r, hipMemsetAsync(r->d_work + 7, 0, sizeof(unsigned), r->stream));
+            ConnRaySource src{r->d_ctag, r->pb[CL2_LIGHT].P0, r->pb[CL2_CAMERA].P0, r->d_chit,
+                              V3{r->cam.focal_point[0], r->cam.focal_point[1], r->cam.focal_point[2]}, B};
+            if (r->counting)
+                hipLaunchKernelGGL((k_traverse_persistent<true, ConnRaySource>), dim3(persistent_grid()), dim3(BLOCK), 0, r->stream,
+                                   r->bvh, r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1);
+            else
+                hipLaunchKernelGGL((k_traverse_persistent<false, ConnRaySource>), dim3(persistent_grid()), dim3(BLOCK), 0, r->stream,
+                                   r->bvh, r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1);
+        } else {
         // grid-stride over the (device-side) ray count; enough workgroups to fill 256 CUs several times over
         const int grid = std::min<size_t>(grid_for((size_t)B * 8), 256 * 32);
         if (r->counting)
@@ -201,6 +238,7 @@ int launch_join(cl2_renderer* r) {
         else
             hipLaunchKernelGGL(k_traverse_conn<false>, dim3(grid), dim3(BLOCK), 0, r->stream, r->bvh, B, r->d_qcount + 7, r->d_ctag,
                                r->pb[CL2_LIGHT].P0, r->pb[CL2_CAMERA].P0, r->cam, r->d_chit, r->d_stats);
+        }
         r->launches_tc++;
     }
     HIP_TRY(r, hipGetLastError());
@@ -313,6 +351,7 @@ int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_render
     A(r->d_hit, B);
     A(r->d_queue, MAX_VERTS * B);
     A(r->d_qcount, 8);
+    A(r->d_work, 8);
     A(r->d_ctag, (size_t)CONN_SLOTS * B);
     A(r->d_chit, (size_t)CONN_SLOTS * B);
     A(r->d_cmask, B);
@@ -567,6 +606,12 @@ int cl2_set_levels_per_launch(cl2_renderer* r, int levels) {
     if (!r) return CL2_E_INVALID;
     if (levels < 1 || levels > MAX_VERTS) return fail(r, CL2_E_INVALID, "levels_per_launch must be 1..6");
     r->levels_per_launch = levels;
+    return CL2_OK;
+}
+int cl2_set_traversal_mode(cl2_renderer* r, int mode) {
+    if (!r) return CL2_E_INVALID;
+    if (mode < 0 || mode > 2) return fail(r, CL2_E_INVALID, "traversal mode must be 0 (auto), 1 (fused) or 2 (split)");
+    r->traversal_mode = mode;
     return CL2_OK;
 }
 int cl2_set_debug_flags(cl2_renderer* r, int flags) { if (!r) return CL2_E_INVALID; r->debug_flags = flags; return CL2_OK; }

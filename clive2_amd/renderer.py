@@ -221,6 +221,10 @@ class Renderer:
         """Bounces traced per launch (1..6); a pure performance knob, results are identical."""
         self._check(self._L.cl2_set_levels_per_launch(self._h, int(levels)), "set_levels_per_launch")
 
+    def set_traversal_mode(self, mode):
+        """0 auto, 1 fused one-ray-per-lane kernels, 2 persistent traversal with ray replacement."""
+        self._check(self._L.cl2_set_traversal_mode(self._h, int(mode)), "set_traversal_mode")
+
     def set_debug_flags(self, flags):
         self._check(self._L.cl2_set_debug_flags(self._h, int(flags)), "set_debug_flags")
 

@@ -104,6 +104,11 @@ int cl2_run_samples(cl2_renderer* r, int n);
  * its state in registers; 1 compacts the survivors after every bounce (pays when most paths die
  * early: open scenes).  Results are identical for every setting. */
 int cl2_set_levels_per_launch(cl2_renderer* r, int levels);
+/* Traversal organisation: 1 = one ray per lane inside the subpath / connection kernels (best when the
+ * tree is LDS-resident), 2 = persistent traversal launches with lane-level ray replacement + one
+ * bounce launch per level (best for large trees: rays of very different cost), 0 = choose by scene
+ * size (default).  Results are identical for every setting. */
+int cl2_set_traversal_mode(cl2_renderer* r, int mode);
 
 /* -- accumulators: Renderer.summed_image / summed_sample_weights / summed_sample_counts /
  *    unidirectional_image_buffer (src/renderer.py:41-45).  Any pointer may be NULL. -- */

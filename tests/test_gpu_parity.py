@@ -153,3 +153,24 @@ def test_levels_per_launch_is_a_pure_performance_knob(levels, glass_scene, oracl
     assert r.counters()["rays"] == o.rays_traced
     with pytest.raises(Exception):
         r.set_levels_per_launch(0)
+
+
+@pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
+def test_persistent_traversal_mode_is_equivalent(scene_name, request, oracle_mod):
+    """traversal_mode 2 (persistent launches with lane-level ray replacement + one bounce launch per
+    level, the large-scene organisation) reproduces the oracle exactly, like the fused mode."""
+    scene = request.getfixturevalue(scene_name)
+    r, o = _pair(scene, oracle_mod)
+    r.set_traversal_mode(2)
+    _run_to_paths(r, o)
+    for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
+        assert r.export_paths(which).tobytes() == ref.tobytes()
+    assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
+    r.join_paths(); o.join_paths()
+    agg = r.export_aggregators()
+    assert agg["total_contribution"].tobytes() == o.weight_aggregators["total_contribution"].tobytes()
+    assert r.counters()["rays"] == o.rays_traced
+    r.set_counting(True)
+    r.run_samples(1)
+    c = r.counters()
+    assert c["box_tests"] > 0 and c["tri_tests"] > 0
