@@ -51,6 +51,21 @@ def cpu_baseline(width, height, samples):
                       f"({o.rays_traced} rays, {dt:.1f} s; C oracle, OpenMP)"}
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note of
+    MI355X_MICROARCH.md); None when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_final_pmc_hbm.json")
+    try:
+        table = json.load(open(path))["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None, None
+    for name, val in table.items():
+        if kernel in name and "true" not in name.split("<")[-1]:
+            return val, "profiles/r01_final_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 1080p Cornell)"
+    return None, None
+
+
 def build_scene(name, W, H):
     import numpy as np
     import clive2_amd as c2
@@ -89,7 +104,7 @@ def main():
     ap.add_argument("--traversal-mode", type=int, default=0, help="0 auto, 1 fused, 2 persistent traversal with ray replacement")
     ap.add_argument("--cpu-width", type=int, default=1920)
     ap.add_argument("--cpu-height", type=int, default=1080)
-    ap.add_argument("--cpu-samples", type=int, default=1)
+    ap.add_argument("--cpu-samples", type=int, default=4)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -179,6 +194,7 @@ def main():
             k_ms, k_rays, k_launches, k_name = (c["ms_traverse_paths"], c["rays_traverse_paths"],
                                                 c["launches_traverse_paths"], "k_traverse_paths")
         achieved = (k_rays * b_ray) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic(k_name) if args.scene == "cornell" and (W, H) == (1920, 1080) else (None, None)
         out = {
             "metric": "Mrays/sec (whole job), 1080p Cornell box BDPT",
             "value": round(rays_total / dt / 1e6, 2),
@@ -192,7 +208,7 @@ def main():
                        "rays_per_pixel_sample": round(rays_local / (args.steps * W * H), 3),
                        "parallelism": f"sample-split x{world}, one {'RCCL' if backend == 'nccl' else backend} all-reduce of the accumulators"},
             "roofline": {"bound": "hbm", "kernel": k_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_ray": round(b_ray, 1), "n_node": round(n_node, 3), "n_tri": round(n_tri, 3),
                          "rays_per_launch": round(k_rays / max(k_launches, 1)),
                          "avg_launch_ms": round(k_ms / max(k_launches, 1), 4)},
