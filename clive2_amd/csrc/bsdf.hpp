@@ -12,7 +12,7 @@
 
 namespace cl2 {
 
-constexpr float PI_F = 3.14159265359f;   // trace.metal:4
+constexpr float PI_F = PI_CONST;         // trace.metal:4
 constexpr float DELTA_F = 0.0001f;       // trace.metal:5
 
 // trace.metal:87-93
@@ -120,7 +120,7 @@ __device__ __forceinline__ float GGX_D(V3 m, V3 n, float alpha) {
 }
 
 // trace.metal:290-292
-__device__ __forceinline__ float reflect_jacobian(V3 m, V3 o) { return 1.0f / (4.0f * __builtin_fabsf(dot(m, o))); }
+__device__ __forceinline__ float reflect_jacobian(V3 m, V3 o) { return rcp_exact(4.0f * __builtin_fabsf(dot(m, o))); }
 
 // trace.metal:294-301 (the `m` argument is unused there too)
 __device__ __forceinline__ float transmit_jacobian(V3 i, V3 o, float ni, float no) {
@@ -161,9 +161,9 @@ __device__ __forceinline__ Bounce diffuse_bounce(V3 wi, V3 n, bool from_camera, 
     orthonormal(n, x, y);
     Bounce b;
     b.wo = random_hemisphere_cosine(x, y, n, rx, ry);
-    b.f = __builtin_fabsf(dot(n, b.wo)) / PI_F;
-    float p_o = __builtin_fabsf(dot(n, b.wo)) / PI_F;
-    float p_i = __builtin_fabsf(dot(n, wi)) / PI_F;
+    b.f = div_pi(__builtin_fabsf(dot(n, b.wo)));
+    float p_o = div_pi(__builtin_fabsf(dot(n, b.wo)));
+    float p_i = div_pi(__builtin_fabsf(dot(n, wi)));
     b.c_p = from_camera ? p_o : p_i;
     b.l_p = from_camera ? p_i : p_o;
     return b;

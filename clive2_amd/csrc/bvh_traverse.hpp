@@ -103,7 +103,7 @@ __device__ __forceinline__ Hit closest_hit_impl(const BvhLds& s, const BvhView& 
                     V3 e1 = v3(a1), e2 = v3(a2);
                     V3 h = cross(d, e2);
                     float a = dot(e1, h);
-                    float f = 1.0f / a;
+                    float f = rcp_exact(a);
                     V3 sv = o - v3(a0);
                     float u = f * dot(sv, h);
                     if (u < 0 || u > 1) continue;
@@ -211,7 +211,7 @@ __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhVi
                 const V3 e1 = v3(a1), e2 = v3(a2);
                 const V3 h = cross(d, e2);
                 const float a = dot(e1, h);
-                const float f = 1.0f / a;
+                const float f = rcp_exact(a);
                 const V3 sv = o - v3(a0);
                 const float u = f * dot(sv, h);
                 if (!(u < 0 || u > 1)) {

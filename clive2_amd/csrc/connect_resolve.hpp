@@ -143,7 +143,7 @@ __device__ __forceinline__ void resolve_pair(
         const LightVtx& a = lv[S - 1];
         const V3 prior_color = lds_v3(LCs, (S - 2) > 0 ? (S - 2) : 0);
         float new_light_f = 1.0f;
-        if (S > 1) new_light_f = __builtin_fabsf(dot(dir_l_to_c, lds_v3(LNs, S - 1))) / PI_F;
+        if (S > 1) new_light_f = div_pi(__builtin_fabsf(dot(dir_l_to_c, lds_v3(LNs, S - 1))));
         const V3 mcol = v3(mats[a.meta & 0xFF].color_type);
         const float shade = new_light_f * Gj / p_s;
         if (light_pixel_idx >= 0 && light_pixel_idx < B && !(debug_flags & 1)) {
@@ -157,13 +157,13 @@ __device__ __forceinline__ void resolve_pair(
     } else {                                                                  // :794-816
         const LightVtx& a = lv[S - 1];
         const MaterialDev cmat = mats[c_meta & 0xFF];
-        const float new_camera_f = __builtin_fabsf(dot(-dir_l_to_c, c_n)) / PI_F;
+        const float new_camera_f = div_pi(__builtin_fabsf(dot(-dir_l_to_c, c_n)));
         const V3 camera_color = (prior_camera_color * new_camera_f) * v3(cmat.color_type);
         V3 light_color;
         if (S == 1) light_color = v3(mats[a.meta & 0xFF].emission_alpha);
         else {
             const V3 prior_light_color = lds_v3(LCs, S >= 2 ? S - 2 : 0);
-            const float new_light_f = __builtin_fabsf(dot(dir_l_to_c, lds_v3(LNs, S - 1))) / PI_F;
+            const float new_light_f = div_pi(__builtin_fabsf(dot(dir_l_to_c, lds_v3(LNs, S - 1))));
             light_color = (prior_light_color * new_light_f) * v3(mats[a.meta & 0xFF].color_type);
         }
         const V3 color = camera_color * light_color;

@@ -615,6 +615,24 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(int B, const float4* __res
     light_image[id] = make_float4(0, 0, 0, 0);
 }
 
+// ---------------------------------------------------------------- exactness self-test
+// Re-runs the proof behind rcp_exact / div_pi on this device: every one of the 2^32 binary32 inputs
+// must give the bits of the IEEE operation.  out[0], out[1] = mismatch counts.
+__global__ void k_selftest_exact_math(unsigned long long* out) {
+    unsigned long long bad_rcp = 0, bad_pi = 0;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < (1ull << 32);
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((unsigned)i);
+        const float r0 = 1.0f / x, r1 = rcp_exact(x);
+        const float p0 = x / PI_CONST, p1 = div_pi(x);
+        const bool nan_r = r0 != r0 && r1 != r1, nan_p = p0 != p0 && p1 != p1;
+        if (!nan_r && __float_as_uint(r0) != __float_as_uint(r1)) bad_rcp++;
+        if (!nan_p && __float_as_uint(p0) != __float_as_uint(p1)) bad_pi++;
+    }
+    if (bad_rcp) atomicAdd(out, bad_rcp);
+    if (bad_pi) atomicAdd(out + 1, bad_pi);
+}
+
 // ---------------------------------------------------------------- debug exports (reference AoS)
 struct RayRec {   // struct Ray, trace.metal:7-23
     float origin[4], direction[4], inv_direction[4], color[4], normal[4];

@@ -608,6 +608,23 @@ int cl2_set_levels_per_launch(cl2_renderer* r, int levels) {
     r->levels_per_launch = levels;
     return CL2_OK;
 }
+int cl2_selftest_exact_math(cl2_renderer* r, uint64_t* rcp_mismatches, uint64_t* divpi_mismatches) {
+    if (!r || !rcp_mismatches || !divpi_mismatches) return CL2_E_INVALID;
+    HIP_TRY(r, hipSetDevice(r->device));
+    unsigned long long* d = nullptr;
+    TRY(dev_alloc(r, &d, (size_t)2));
+    int rc = CL2_OK;
+    if (hipMemset(d, 0, 16) != hipSuccess) rc = fail(r, CL2_E_HIP, "selftest memset failed");
+    if (rc == CL2_OK) {
+        hipLaunchKernelGGL(k_selftest_exact_math, dim3(4096), dim3(BLOCK), 0, r->stream, d);
+        rc = drain(r);
+    }
+    unsigned long long h[2] = {0, 0};
+    if (rc == CL2_OK && hipMemcpy(h, d, 16, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(r, CL2_E_HIP, "selftest copy failed");
+    dev_free(r, d);
+    *rcp_mismatches = h[0]; *divpi_mismatches = h[1];
+    return rc;
+}
 int cl2_set_traversal_mode(cl2_renderer* r, int mode) {
     if (!r) return CL2_E_INVALID;
     if (mode < 0 || mode > 2) return fail(r, CL2_E_INVALID, "traversal mode must be 0 (auto), 1 (fused) or 2 (split)");

@@ -221,6 +221,12 @@ class Renderer:
         """Bounces traced per launch (1..6); a pure performance knob, results are identical."""
         self._check(self._L.cl2_set_levels_per_launch(self._h, int(levels)), "set_levels_per_launch")
 
+    def selftest_exact_math(self):
+        """(rcp mismatches, x/pi mismatches) over all 2^32 float inputs; both must be 0."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._L.cl2_selftest_exact_math(self._h, C.byref(a), C.byref(b)), "selftest_exact_math")
+        return a.value, b.value
+
     def set_traversal_mode(self, mode):
         """0 auto, 1 fused one-ray-per-lane kernels, 2 persistent traversal with ray replacement."""
         self._check(self._L.cl2_set_traversal_mode(self._h, int(mode)), "set_traversal_mode")

@@ -132,6 +132,11 @@ int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
 int cl2_set_debug_flags(cl2_renderer* r, int flags);
 int cl2_reset_counters(cl2_renderer* r);
 
+/* Exactness self-test: the kernels replace `1.0f/a` and `x/PI` by cheaper sequences that are proven
+ * (exhaustively, over all 2^32 binary32 inputs) to return the correctly rounded IEEE result; this call
+ * re-runs that proof on the device and returns the number of inputs that disagree (must be 0, 0). */
+int cl2_selftest_exact_math(cl2_renderer* r, uint64_t* rcp_mismatches, uint64_t* divpi_mismatches);
+
 /* -- debug exports in the reference's AoS layouts (stage-level parity) -- */
 int cl2_export_rays(cl2_renderer* r, int which, void* out_rays, size_t n_records);        /* Ray[batch]  */
 int cl2_export_paths(cl2_renderer* r, int which, void* out_paths, size_t n_records);      /* Path[batch] */

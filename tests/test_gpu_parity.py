@@ -174,3 +174,9 @@ def test_persistent_traversal_mode_is_equivalent(scene_name, request, oracle_mod
     r.run_samples(1)
     c = r.counters()
     assert c["box_tests"] > 0 and c["tri_tests"] > 0
+
+
+def test_exact_reciprocal_and_div_pi_proof(cornell_small):
+    """rcp_exact / div_pi (csrc/vecmath.hpp) return the IEEE-correct bits for all 2^32 inputs."""
+    from clive2_amd.renderer import Renderer
+    assert Renderer(cornell_small).selftest_exact_math() == (0, 0)
