@@ -128,7 +128,8 @@ int cl2_set_profiling(cl2_renderer* r, int on);     /* HIP-event timers per stag
 int cl2_set_counting(cl2_renderer* r, int on);      /* node / triangle test tallies in the traversal kernels */
 int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
 /* performance-experiment switches; results are NOT valid renders when any bit is set.
- * bit 0: skip the t=1 light-image splat atomics. */
+ * bit 0: skip the t=1 light-image splat atomics; bit 1 / bit 2: skip the t >= 2 / t == 1 strategy pairs in
+ * the resolve kernel; bits 4-6: register budget variant of the resolve kernel. */
 int cl2_set_debug_flags(cl2_renderer* r, int flags);
 int cl2_reset_counters(cl2_renderer* r);
 

@@ -125,3 +125,20 @@ def test_presets_and_turntable():
     np.testing.assert_allclose(cam["center"][:3], [7.5, 1.5, 0], atol=1e-6)
     np.testing.assert_allclose(cam["direction"][:3], [-1, 0, 0], atol=1e-6)
     assert len(s.triangles) == 16 and s.validate()
+
+
+def test_scene_from_mesh_files(tmp_path):
+    """file_specs with .ply / .obj paths (scene.py:49-66) go through the package's own readers."""
+    from clive2_amd.meshes import icosphere
+    from clive2_amd import meshio
+    v, f = icosphere(1, radius=1.0)
+    ply, obj = str(tmp_path / "s.ply"), str(tmp_path / "s.obj")
+    meshio.write_ply(ply, v, f)
+    meshio.write_obj(obj, v, f)
+    specs = [dict(file_path=ply, offset=np.array([-3.0, 0, 0]), material=5, scale=1.5),
+             dict(file_path=obj, offset=np.array([3.0, 0, 0]), material=0)]
+    s = c2.create_scene(32, 24, np.array([0, 1.5, 6]), np.array([0, 0, -1]), file_specs=specs)
+    assert len(s.triangles) == 16 + 2 * 80 and s.validate()
+    assert sorted(set(s.triangles["material"])) == [0, 1, 2, 3, 4, 5, 6, 7]
+    with pytest.raises(NotImplementedError):
+        c2.create_scene(8, 8, np.zeros(3), np.array([0, 0, 1.0]), file_specs=[dict(file_path="mesh.stl")])
