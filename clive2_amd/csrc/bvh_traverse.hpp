@@ -1,4 +1,4 @@
-// bvh_traverse.hpp -- closest-hit BVH query, stackless, with the top of the tree staged in LDS.
+// bvh_traverse.hpp -- closest-hit BVH query, stackless, nodes in visit order, top of the array in LDS.
 //
 // Reference semantics (`src/trace.metal:106-176`): slab box test that returns the entry distance,
 // Moller-Trumbore triangle test (reject t <= DELTA, inclusive u,v bounds, no parallel-ray guard),
@@ -6,20 +6,24 @@
 // its entry distance is not < best_t, scans leaf triangles in ascending order and keeps a hit
 // only on strict t < best_t.
 //
-// MI355X formulation: the reference's 64-entry per-thread stack would live in scratch memory.
-// Instead every node carries a SKIP link (the node the reference's stack would pop next if this
-// subtree were abandoned), computed once at scene upload.  Walking "hit inner -> left+1, else
-// -> skip" visits exactly the nodes the stack version visits, in the same order, testing each
-// against the same best_t -- so hits (including exact-t ties) are identical -- with no stack
-// and no scratch traffic.  Nodes [0, n_lds_nodes) (breadth-first = the top levels) and, when
-// they fit, all intersection triangles are copied into LDS by each workgroup.
+// MI355X formulation.  The reference's 64-entry per-thread stack would live in scratch memory.
+// Instead the nodes are re-ordered at scene upload into the reference's own VISIT order (node, right
+// subtree, left subtree), so that
+//     hit on an inner node  -> next node is index + 1            (same or next cache line)
+//     miss / leaf finished  -> next node is `skip` = index + size of this subtree
+// which visits exactly the nodes the stack version visits, in the same order, testing each against
+// the same best_t -- hits (including exact-t ties) are identical -- with no stack, no scratch
+// traffic, ONE 32-byte record per step and sequential addresses while a ray descends.  Records
+// [0, n_lds_nodes) and, when they fit, all intersection triangles are copied into LDS by each
+// workgroup (the whole Cornell box: 5 nodes + 16 triangles).
 //
-// Device layouts (built by Renderer::upload_scene):
-//   node   : float4 lo = {min.xyz, as_float(left)}, float4 hi = {max.xyz, as_float(right)}  (32 B)
-//            right == 0 -> inner (children left, left+1); else leaf over triangles [left, right)
-//   skip   : int32 per node, -1 terminates
-//   tri    : 3 x float4 = {v0.xyz,-}, {e1.xyz,-}, {e2.xyz,-} with e1 = v1-v0, e2 = v2-v0 (the same
-//            float32 subtractions the reference performs per test, done once)
+// Device layouts (built by cl2_upload_scene):
+//   node : float4 lo = {min.xyz, as_float(skip)}, float4 hi = {max.xyz, as_float(info)}      (32 B)
+//          info < 0: inner node.  info >= 0: leaf over triangles [info >> 4, (info >> 4) + (info & 15) + 1).
+//          A reference leaf with more than 16 triangles (only possible past the builder's depth
+//          limit) continues in follow-up records whose box is (-inf, +inf): always entered.
+//   tri  : 3 x float4 = {v0.xyz,-}, {e1.xyz,-}, {e2.xyz,-} with e1 = v1-v0, e2 = v2-v0 (the same
+//          float32 subtractions the reference performs per test, done once); reference order.
 #pragma once
 #include "vecmath.hpp"
 #include "bsdf.hpp"
@@ -27,29 +31,27 @@
 namespace cl2 {
 
 struct BvhView {
-    const float4* nodes;     // 2 float4 per node
-    const int* skip;
+    const float4* nodes;     // 2 float4 per node, visit order
     const float4* tris;      // 3 float4 per triangle
-    int n_nodes;
+    int n_nodes;             // records (>= reference boxes when oversized leaves were split)
     int n_tris;
-    int n_lds_nodes;         // nodes staged in LDS (<= LDS_NODE_CAP)
+    int n_lds_nodes;         // records staged in LDS (<= LDS_NODE_CAP)
     int lds_tris;            // 1: all triangles staged in LDS (n_tris <= LDS_TRI_CAP)
 };
 
-constexpr int LDS_NODE_CAP = 256;   // 256 * (32 + 4) B = 9 KB
+constexpr int LDS_NODE_CAP = 256;   // 256 * 32 B = 8 KB
 constexpr int LDS_TRI_CAP = 128;    // 128 * 48 B = 6 KB
+constexpr int LEAF_PACK_MAX = 16;   // triangles per leaf record
 
 struct BvhLds {
     float4 nodes[2 * LDS_NODE_CAP];
     float4 tris[3 * LDS_TRI_CAP];
-    int skip[LDS_NODE_CAP];
 };
 
 // Cooperative copy of the staged part of the tree; every thread of the block must call it.
 __device__ __forceinline__ void stage_bvh(BvhLds& s, const BvhView& b) {
     const int nt = blockDim.x, t = threadIdx.x;
     for (int i = t; i < 2 * b.n_lds_nodes; i += nt) s.nodes[i] = b.nodes[i];
-    for (int i = t; i < b.n_lds_nodes; i += nt) s.skip[i] = b.skip[i];
     if (b.lds_tris)
         for (int i = t; i < 3 * b.n_tris; i += nt) s.tris[i] = b.tris[i];
     __syncthreads();
@@ -71,11 +73,12 @@ __device__ __forceinline__ Hit closest_hit_impl(const BvhLds& s, const BvhView& 
                                                unsigned& n_box, unsigned& n_tri) {
     Hit best{-1, __builtin_inff(), 0.0f, 0.0f};
     int node = 0;
-    while (node >= 0) {
+    const int n_nodes = b.n_nodes;
+    while (node < n_nodes) {
         float4 lo, hi;
-        int next;
-        if (ALL_LDS || node < b.n_lds_nodes) { lo = s.nodes[2 * node]; hi = s.nodes[2 * node + 1]; next = s.skip[node]; }
-        else { lo = b.nodes[2 * node]; hi = b.nodes[2 * node + 1]; next = b.skip[node]; }
+        if (ALL_LDS || node < b.n_lds_nodes) { lo = s.nodes[2 * node]; hi = s.nodes[2 * node + 1]; }
+        else { lo = b.nodes[2 * node]; hi = b.nodes[2 * node + 1]; }
+        int next = __float_as_int(lo.w);                   // skip: first record after this subtree
         if (COUNT) n_box++;
         // ray_box_intersect, trace.metal:106-115 (called with t = INFINITY, :153-155)
         float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
@@ -90,10 +93,11 @@ __device__ __forceinline__ Hit closest_hit_impl(const BvhLds& s, const BvhView& 
             tmax = min_msl(min_msl(max_msl(t0x, t1x), max_msl(t0y, t1y)), min_msl(max_msl(t0z, t1z), __builtin_inff()));
         }
         if (tmin <= tmax && tmin < best.t) {
-            const int left = __float_as_int(lo.w), right = __float_as_int(hi.w);
-            if (right == 0) {
-                next = left + 1;                       // right child first (trace.metal:158-159)
+            const int info = __float_as_int(hi.w);
+            if (info < 0) {
+                next = node + 1;                       // right child first (trace.metal:158-159): adjacent record
             } else {
+                const int left = info >> 4, right = left + (info & 15) + 1;
                 for (int i = left; i < right; i++) {   // trace.metal:161-172
                     float4 a0, a1, a2;
                     if (ALL_LDS || b.lds_tris) { a0 = s.tris[3 * i]; a1 = s.tris[3 * i + 1]; a2 = s.tris[3 * i + 2]; }
@@ -165,7 +169,8 @@ __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhVi
     bool active = false, fast = true;
     V3 o = v3(0, 0, 0), d = o, inv = o;
     Hit best{-1, __builtin_inff(), 0.0f, 0.0f};
-    int node = -1, tri_i = 0, tri_end = 0;
+    const int n_nodes = b.n_nodes;
+    int node = n_nodes, tri_i = 0, tri_end = 0;
     unsigned key = 0;
 
     while (true) {
@@ -222,12 +227,12 @@ __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhVi
                         if (t > DELTA_F && t < best.t) { best.tri = i; best.t = t; best.u = u; best.v = v; }
                     }
                 }
-            } else if (node >= 0) {
+            } else if (node < n_nodes) {
                 // one node: ray_box_intersect + descend / skip (trace.metal:150-160)
                 float4 lo, hi;
-                int next;
-                if (node < b.n_lds_nodes) { lo = s.nodes[2 * node]; hi = s.nodes[2 * node + 1]; next = s.skip[node]; }
-                else { lo = b.nodes[2 * node]; hi = b.nodes[2 * node + 1]; next = b.skip[node]; }
+                if (node < b.n_lds_nodes) { lo = s.nodes[2 * node]; hi = s.nodes[2 * node + 1]; }
+                else { lo = b.nodes[2 * node]; hi = b.nodes[2 * node + 1]; }
+                const int cur = node, next = __float_as_int(lo.w);
                 if (COUNT) n_box++;
                 const float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
                 const float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
@@ -242,9 +247,9 @@ __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhVi
                 }
                 node = next;
                 if (tmin <= tmax && tmin < best.t) {
-                    const int left = __float_as_int(lo.w), right = __float_as_int(hi.w);
-                    if (right == 0) node = left + 1;
-                    else { tri_i = left; tri_end = right; }
+                    const int info = __float_as_int(hi.w);
+                    if (info < 0) node = cur + 1;
+                    else { tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
                 }
             } else {
                 src.store(key, best);

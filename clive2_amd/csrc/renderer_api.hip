@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -52,7 +53,7 @@ struct cl2_renderer {
     // scene
     BvhView bvh{};
     float4 *d_nodes = nullptr, *d_tris = nullptr, *d_tri_shade = nullptr, *d_light_tris = nullptr;
-    int *d_skip = nullptr, *d_light_tri_index = nullptr;
+    int* d_light_tri_index = nullptr;
     float* d_light_areas = nullptr;
     MaterialDev* d_mats = nullptr;
     int n_mats = 0, light_count = 0;
@@ -403,6 +404,7 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     if (!boxes_v || !tris_v || !mats_v || !camera_v || !light_tris_v || !light_areas || !light_tri_index)
         return fail(r, CL2_E_INVALID, "NULL scene array");
     if (n_boxes < 1 || n_tris < 1 || light_count < 1) return fail(r, CL2_E_INVALID, "scene needs >=1 box, triangle and light");
+    if (n_tris >= (1 << 27)) return fail(r, CL2_E_INVALID, "at most 2^27 triangles (leaf records pack begin<<4 | count-1)");
     // material 7 is hard-wired into the camera vertices (trace.metal:611, :1053); at most 256 fit the packed meta word
     if (n_mats < 8 || n_mats > 256) return fail(r, CL2_E_INVALID, "material table must have 8..256 entries");
     const BoxRec* boxes = static_cast<const BoxRec*>(boxes_v);
@@ -414,22 +416,38 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     if (cam.pixel_width != r->W || cam.pixel_height != r->H)
         return fail(r, CL2_E_INVALID, "camera resolution differs from the renderer's");
 
-    // ---- validate the tree: every index in range and children after their parent (breadth-first
-    // numbering, src/bvh.py:345-351), which also guarantees the stackless walk terminates ----
-    std::vector<int> skip(n_boxes, -2);
-    std::vector<char> tri_seen(n_tris, 0);
-    skip[0] = -1;
+    // ---- validate the tree: every index in range, children after their parent (breadth-first
+    // numbering, src/bvh.py:345-351) and every box reached exactly once -- which also guarantees
+    // that the stackless walk terminates ----
+    std::vector<char> reached(n_boxes, 0);
+    reached[0] = 1;
     for (int i = 0; i < n_boxes; i++) {
         const BoxRec& b = boxes[i];
-        if (skip[i] == -2) return fail(r, CL2_E_INVALID, "box " + std::to_string(i) + " is not reachable from the root");
+        if (!reached[i]) return fail(r, CL2_E_INVALID, "box " + std::to_string(i) + " is not reachable from the root");
         if (b.right == 0) {
             if (b.left <= i || b.left + 1 >= n_boxes) return fail(r, CL2_E_INVALID, "inner box child index out of order/range");
-            if (skip[b.left] != -2 || skip[b.left + 1] != -2) return fail(r, CL2_E_INVALID, "box has two parents");
-            skip[b.left + 1] = b.left;     // right child is visited first; then its sibling
-            skip[b.left] = skip[i];        // after the left child, whatever followed the parent
+            if (reached[b.left] || reached[b.left + 1]) return fail(r, CL2_E_INVALID, "box has two parents");
+            reached[b.left] = reached[b.left + 1] = 1;
         } else {
             if (b.left < 0 || b.right > n_tris || b.left >= b.right) return fail(r, CL2_E_INVALID, "leaf triangle range out of range");
-            for (int t = b.left; t < b.right; t++) tri_seen[t] = 1;
+        }
+    }
+    // ---- visit order (node, right subtree, left subtree = the reference's pop order, trace.metal:150-160)
+    // and subtree sizes in records; leaves with more than LEAF_PACK_MAX triangles take extra records ----
+    auto leaf_records = [&](const BoxRec& b) { return (b.right - b.left + LEAF_PACK_MAX - 1) / LEAF_PACK_MAX; };
+    std::vector<int> subtree(n_boxes, 0);
+    for (int i = n_boxes - 1; i >= 0; i--) {            // children have larger indices than their parent
+        const BoxRec& b = boxes[i];
+        subtree[i] = b.right == 0 ? 1 + subtree[b.left] + subtree[b.left + 1] : leaf_records(b);
+    }
+    const int n_records = subtree[0];
+    std::vector<int> rec_index(n_boxes, -1);
+    rec_index[0] = 0;
+    for (int i = 0; i < n_boxes; i++) {                  // parents before children: their record index is known
+        const BoxRec& b = boxes[i];
+        if (b.right == 0) {
+            rec_index[b.left + 1] = rec_index[i] + 1;                            // right child: adjacent
+            rec_index[b.left] = rec_index[i] + 1 + subtree[b.left + 1];          // left child: after the right subtree
         }
     }
     for (int t = 0; t < n_tris; t++) {
@@ -441,13 +459,30 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     }
 
     // ---- repack ----
-    std::vector<float4> h_nodes(2 * (size_t)n_boxes), h_tris(3 * (size_t)n_tris), h_shade(4 * (size_t)n_tris),
+    std::vector<float4> h_nodes(2 * (size_t)n_records), h_tris(3 * (size_t)n_tris), h_shade(4 * (size_t)n_tris),
         h_ltris(5 * (size_t)light_count);
     auto as_f = [](int32_t i) { float f; std::memcpy(&f, &i, 4); return f; };
+    const float inf = std::numeric_limits<float>::infinity();
     for (int i = 0; i < n_boxes; i++) {
         const BoxRec& b = boxes[i];
-        h_nodes[2 * i] = make_float4(b.min[0], b.min[1], b.min[2], as_f(b.left));
-        h_nodes[2 * i + 1] = make_float4(b.max[0], b.max[1], b.max[2], as_f(b.right));
+        const int k = rec_index[i], skip = k + subtree[i];
+        if (b.right == 0) {
+            h_nodes[2 * (size_t)k] = make_float4(b.min[0], b.min[1], b.min[2], as_f(skip));
+            h_nodes[2 * (size_t)k + 1] = make_float4(b.max[0], b.max[1], b.max[2], as_f(-1));
+        } else {
+            int begin = b.left;
+            for (int part = 0; begin < b.right; part++, begin += LEAF_PACK_MAX) {
+                const int count = std::min(LEAF_PACK_MAX, b.right - begin);
+                const int info = (begin << 4) | (count - 1);
+                // follow-up records of an oversized leaf: an unbounded box, so they are always entered
+                const float4 lo = part == 0 ? make_float4(b.min[0], b.min[1], b.min[2], as_f(k + part + 1))
+                                            : make_float4(-inf, -inf, -inf, as_f(k + part + 1));
+                const float4 hi = part == 0 ? make_float4(b.max[0], b.max[1], b.max[2], as_f(info))
+                                            : make_float4(inf, inf, inf, as_f(info));
+                h_nodes[2 * (size_t)(k + part)] = lo;
+                h_nodes[2 * (size_t)(k + part) + 1] = hi;
+            }
+        }
     }
     for (int t = 0; t < n_tris; t++) {
         const TriRec& T = tris[t];
@@ -479,10 +514,9 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     HIP_TRY(r, hipSetDevice(r->device));
     HIP_TRY(r, hipStreamSynchronize(r->stream));
     r->scene_ok = false;
-    dev_free(r, r->d_nodes); dev_free(r, r->d_skip); dev_free(r, r->d_tris); dev_free(r, r->d_tri_shade);
+    dev_free(r, r->d_nodes); dev_free(r, r->d_tris); dev_free(r, r->d_tri_shade);
     dev_free(r, r->d_mats); dev_free(r, r->d_light_tris); dev_free(r, r->d_light_areas); dev_free(r, r->d_light_tri_index);
     TRY(dev_alloc(r, &r->d_nodes, h_nodes.size()));
-    TRY(dev_alloc(r, &r->d_skip, skip.size()));
     TRY(dev_alloc(r, &r->d_tris, h_tris.size()));
     TRY(dev_alloc(r, &r->d_tri_shade, h_shade.size()));
     TRY(dev_alloc(r, &r->d_mats, h_mats.size()));
@@ -490,7 +524,6 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     TRY(dev_alloc(r, &r->d_light_areas, (size_t)light_count));
     TRY(dev_alloc(r, &r->d_light_tri_index, (size_t)light_count));
     HIP_TRY(r, hipMemcpy(r->d_nodes, h_nodes.data(), h_nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_TRY(r, hipMemcpy(r->d_skip, skip.data(), skip.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(r, hipMemcpy(r->d_tris, h_tris.data(), h_tris.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(r, hipMemcpy(r->d_tri_shade, h_shade.data(), h_shade.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(r, hipMemcpy(r->d_mats, h_mats.data(), h_mats.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
@@ -498,9 +531,9 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     HIP_TRY(r, hipMemcpy(r->d_light_areas, light_areas, (size_t)light_count * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(r, hipMemcpy(r->d_light_tri_index, light_tri_index, (size_t)light_count * sizeof(int), hipMemcpyHostToDevice));
 
-    r->bvh.nodes = r->d_nodes; r->bvh.skip = r->d_skip; r->bvh.tris = r->d_tris;
-    r->bvh.n_nodes = n_boxes; r->bvh.n_tris = n_tris;
-    r->bvh.n_lds_nodes = std::min(n_boxes, LDS_NODE_CAP);
+    r->bvh.nodes = r->d_nodes; r->bvh.tris = r->d_tris;
+    r->bvh.n_nodes = n_records; r->bvh.n_tris = n_tris;
+    r->bvh.n_lds_nodes = std::min(n_records, LDS_NODE_CAP);
     r->bvh.lds_tris = n_tris <= LDS_TRI_CAP ? 1 : 0;
     r->n_mats = n_mats; r->light_count = light_count; r->cam = cam;
     r->scene_ok = true;
