@@ -157,12 +157,17 @@ __device__ __forceinline__ Hit closest_hit(const BvhLds& s, const BvhView& b, V3
 // of node visits, triangle tests and comparisons of each ray is exactly that of closest_hit_impl.
 namespace cl2 {
 
-constexpr int RAY_CHUNK = 512;      // rays handed to a wave per global atomic
+constexpr int RAY_CHUNK_MAX = 512;  // rays handed to a wave per global atomic: 64..512, about a quarter of a wave's fair share
 
 template <bool COUNT, class Source>
 __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhView& b, unsigned n, unsigned* work_counter,
                                                     const Source& src, unsigned& n_box, unsigned& n_tri) {
     const int lane = threadIdx.x & 63;
+    // chunk size: small launches (one subpath level = one ray per pixel) must still spread over every
+    // wave and leave rays for replacement; big launches amortise the atomic
+    const unsigned waves = gridDim.x * (blockDim.x >> 6);
+    unsigned chunk = n / (waves * 4u);
+    chunk = chunk < 64u ? 64u : (chunk > (unsigned)RAY_CHUNK_MAX ? (unsigned)RAY_CHUNK_MAX : chunk);
     unsigned w_next = 0, w_end = 0;            // wave-uniform: current chunk [w_next, w_end)
     bool dry = false;                          // wave-uniform: the launch has no rays left
     // per-lane ray state
@@ -179,11 +184,11 @@ __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhVi
         while (idle && !dry) {
             if (w_next >= w_end) {             // wave-uniform branch: fetch a new chunk
                 unsigned base = 0;
-                if (lane == 0) base = atomicAdd(work_counter, (unsigned)RAY_CHUNK);
+                if (lane == 0) base = atomicAdd(work_counter, chunk);
                 base = __shfl(base, 0);
                 if (base >= n) { dry = true; break; }
                 w_next = base;
-                w_end = base + RAY_CHUNK < n ? base + RAY_CHUNK : n;
+                w_end = base + chunk < n ? base + chunk : n;
             }
             const unsigned avail = w_end - w_next;
             const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
