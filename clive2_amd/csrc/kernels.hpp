@@ -1,21 +1,24 @@
-// kernels.hpp -- wavefront bidirectional path tracing kernels for gfx950 (MI355X).
+// kernels.hpp -- bidirectional path tracing kernels for gfx950 (MI355X).
 //
 // The reference runs the per-sample pipeline as two megakernels (`generate_paths`,
 // `connect_paths`, src/trace.metal:381-532, :620-869) that keep whole 1040-byte Path records in
 // thread-private memory, followed by a 300-launch bitonic sort + host bincount to splat the light
-// image.  Here the same arithmetic is a WAVEFRONT pipeline over SoA state:
+// image.  Here the same arithmetic runs as a short sequence of launches over SoA state:
 //
-//   gen_light_rays / gen_camera_rays         vertex slot 0 of each subpath        (K1, K2)
-//   6 x { traverse_paths ; bounce }          per subpath kind; survivors are compacted into the
-//                                            next level's queue with wave ballots  (K3)
-//   connect_setup                            enumerate (t,s) strategy pairs, cull, emit a compacted
-//                                            queue of connection rays             (K5, first half)
-//   traverse_conn                            closest hit for every connection ray
-//   connect_resolve                          MIS weights + contributions per pixel in the
+//   k_gen_light_rays / k_gen_camera_rays     vertex slot 0 of each subpath                   (K1, K2)
+//   k_trace_subpath<cam> levels [first,end)  closest hit + bounce, walking state in registers; the
+//                                            survivors of a launch are compacted into the next
+//                                            launch's queue with wave ballots                   (K3)
+//     large trees: k_traverse_persistent (lane-level ray replacement) + k_trace_subpath<EXT_HIT>
+//   k_connect_setup                          enumerate (t,s) strategy pairs, cull, emit a compacted
+//                                            queue of connection-ray tags                (K5, culls)
+//   k_traverse_conn / k_traverse_persistent  closest hit for every connection ray
+//   k_connect_resolve (connect_resolve.hpp)  MIS weights + contributions per pixel in the
 //                                            reference's (t,s) order; t=1 splats by float atomics
 //                                            (replaces K4, K7 x300, host bincount, K8)
-//   finalize / accumulate                    3x3 reconstruction filter, on-device accumulators (K6,
+//   k_finalize / k_accumulate                3x3 reconstruction filter, on-device accumulators (K6,
 //                                            renderer.py:253-278)
+//   k_traverse_paths                         closest-hit probe (cl2_probe_traverse)
 //
 // Path-vertex SoA (per subpath kind, slot v in [0,6), pixel p; index v*B + p):
 //   P0 = {origin.xyz, c_importance}  P1 = {direction.xyz, l_importance}
