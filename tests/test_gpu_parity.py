@@ -180,3 +180,49 @@ def test_exact_reciprocal_and_div_pi_proof(cornell_small):
     """rcp_exact / div_pi (csrc/vecmath.hpp) return the IEEE-correct bits for all 2^32 inputs."""
     from clive2_amd.renderer import Renderer
     assert Renderer(cornell_small).selftest_exact_math() == (0, 0)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_oversized_leaves_and_big_material_table(mode, oracle_mod):
+    """Hand-made tree: root with two leaves of 48 triangles each (a reference leaf may exceed 8 when
+    the builder's depth limit trips, bvh.py:294) -> each leaf spans several 16-triangle device
+    records; plus a 40-entry material table (beyond the LDS-staged 32)."""
+    import clive2_amd as c2
+    from clive2_amd import struct_types as st
+    from clive2_amd.load import get_materials
+    from clive2_amd.meshes import icosphere
+    from clive2_amd.renderer import Renderer, make_seeds
+    v, f = icosphere(1, radius=2.0, center=(0.0, 1.0, 0.0))
+    mats = np.zeros(40, dtype=st.Material)
+    mats[:8] = get_materials()
+    mats[8:] = mats[4]
+    mats["alpha"][5] = 0.2
+    scene = c2.create_scene(48, 32, np.array([0, 1.5, 6]), np.array([0, 0, -1]),
+                            file_specs=[dict(mesh=(v, f), material=5)], materials=mats)
+    n = len(scene.triangles)
+    assert n == 96
+    tri = scene.triangles
+    tri["material"][tri["material"] == 4] = 39                      # use a material beyond the LDS cap
+    boxes = np.zeros(3, dtype=st.Box)
+    pts = np.stack([tri["v0"], tri["v1"], tri["v2"]])[..., :3]
+    for i, (a, b) in enumerate(((0, n), (0, 48), (48, n))):
+        boxes["min"][i, :3] = pts[:, a:b].min(axis=(0, 1))
+        boxes["max"][i, :3] = pts[:, a:b].max(axis=(0, 1))
+    boxes["left"][0], boxes["right"][0] = 1, 0
+    boxes["left"][1], boxes["right"][1] = 0, 48
+    boxes["left"][2], boxes["right"][2] = 48, n
+    scene.boxes = boxes
+    assert scene.validate()
+    seeds = make_seeds(48 * 32)
+    r, o = Renderer(scene, seeds=seeds), oracle_mod.OracleRenderer(scene, seeds=seeds)
+    r.set_traversal_mode(mode)
+    _run_to_paths(r, o)
+    for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
+        assert r.export_paths(which).tobytes() == ref.tobytes()
+    r.join_paths(); o.join_paths()
+    assert r.export_aggregators()["total_contribution"].tobytes() == o.weight_aggregators["total_contribution"].tobytes()
+    assert r.counters()["rays"] == o.rays_traced
+    r.set_counting(True); r.run_samples(1)
+    c = r.counters()
+    # 3 reference boxes -> 1 + 3 + 3 device records; box tests count records, triangle tests match the reference
+    assert c["tri_tests"] > 0 and c["box_tests"] >= c["counted_rays"]
