@@ -44,7 +44,8 @@ struct cl2_renderer {
     int device = 0, W = 0, H = 0, B = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    bool scene_ok = false, profiling = false, counting = false;
+    bool scene_ok = false, counting = false;
+    int profiling = 0;                   // 0 off, 1 traversal launches only, 2 every stage
     int debug_flags = 0;
     int traversal_mode = 0;              // 0 auto, 1 fused (one ray per lane), 2 split (persistent traversal + ray replacement)
     unsigned* d_work = nullptr;          // [8] work counters of the persistent traversal launches
@@ -128,7 +129,8 @@ hipEvent_t take_event(cl2_renderer* r) {
 struct Timed {   // records a HIP-event span around a launch when profiling is on
     cl2_renderer* r; int stage; hipEvent_t a = nullptr;
     Timed(cl2_renderer* r_, int st) : r(r_), stage(st) {
-        if (r->profiling) { a = take_event(r); (void)hipEventRecord(a, r->stream); }
+        const bool wanted = r->profiling >= 2 || (r->profiling == 1 && (st == ST_TRAVERSE_CONN || st == ST_TRAVERSE_PATHS));
+        if (wanted) { a = take_event(r); (void)hipEventRecord(a, r->stream); }
     }
     ~Timed() {
         if (a) { hipEvent_t b = take_event(r); (void)hipEventRecord(b, r->stream); r->spans.push_back({a, b, stage}); }
@@ -634,7 +636,11 @@ int cl2_write_accumulators_packed(cl2_renderer* r, const float* src, size_t n) {
 int cl2_copy_accumulators_to_device(cl2_renderer* r, void* dst, size_t n) { return acc_copy(r, dst, r ? r->d_acc : nullptr, n, hipMemcpyDeviceToDevice); }
 int cl2_copy_accumulators_from_device(cl2_renderer* r, const void* src, size_t n) { return acc_copy(r, r ? r->d_acc : nullptr, src, n, hipMemcpyDeviceToDevice); }
 
-int cl2_set_profiling(cl2_renderer* r, int on) { if (!r) return CL2_E_INVALID; r->profiling = on != 0; return CL2_OK; }
+int cl2_set_profiling(cl2_renderer* r, int level) {
+    if (!r) return CL2_E_INVALID;
+    r->profiling = level < 0 ? 0 : (level > 2 ? 2 : level);
+    return CL2_OK;
+}
 int cl2_set_levels_per_launch(cl2_renderer* r, int levels) {
     if (!r) return CL2_E_INVALID;
     if (levels < 1 || levels > MAX_VERTS) return fail(r, CL2_E_INVALID, "levels_per_launch must be 1..6");

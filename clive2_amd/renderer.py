@@ -211,8 +211,10 @@ class Renderer:
             self.load_packed_accumulators(allreduce_packed_host(self.packed_accumulators(), group))
 
     # ---- counters / profiling ----
-    def set_profiling(self, on=True):
-        self._check(self._L.cl2_set_profiling(self._h, int(bool(on))), "set_profiling")
+    def set_profiling(self, level=2):
+        """HIP-event stage timers: 0 off, 1 the traversal launches only, 2 (or True) every stage."""
+        level = 2 if level is True else int(level)
+        self._check(self._L.cl2_set_profiling(self._h, level), "set_profiling")
 
     def set_counting(self, on=True):
         self._check(self._L.cl2_set_counting(self._h, int(bool(on))), "set_counting")
