@@ -226,3 +226,56 @@ def test_oversized_leaves_and_big_material_table(mode, oracle_mod):
     c = r.counters()
     # 3 reference boxes -> 1 + 3 + 3 device records; box tests count records, triangle tests match the reference
     assert c["tri_tests"] > 0 and c["box_tests"] >= c["counted_rays"]
+
+
+def test_all_material_types_bit_exact(oracle_mod):
+    """Material types the shipped table never reaches: type 1 with alpha 0 (smooth
+    dielectric through the general GGX route), type 2 (Fresnel-weighted reflect / diffuse), type >= 3
+    (always reflect), each on its own sphere, alpha 0 / 0.3 / 0.05 (trace.metal:474-487)."""
+    import clive2_amd as c2
+    from clive2_amd import struct_types as st
+    from clive2_amd.load import get_materials
+    from clive2_amd.meshes import icosphere
+    from clive2_amd.renderer import Renderer, make_seeds
+    mats = np.zeros(10, dtype=st.Material)
+    mats[:8] = get_materials()
+    mats[8], mats[9] = mats[5], mats[5]
+    mats["type"][8], mats["alpha"][8] = 2, 0.3
+    mats["type"][9], mats["alpha"][9] = 3, 0.05
+    mats["color"][9, :3] = (0.9, 0.9, 0.9)
+    specs = [dict(mesh=icosphere(2, radius=1.6, center=(x, 0.0, z)), material=m)
+             for x, z, m in ((-3.5, 0.0, 0), (0.0, -1.0, 8), (3.5, 0.0, 9))]
+    scene = c2.create_scene(96, 64, np.array([0, 1.5, 6]), np.array([0, 0, -1]), file_specs=specs, materials=mats)
+    seeds = make_seeds(96 * 64)
+    r, o = Renderer(scene, seeds=seeds), oracle_mod.OracleRenderer(scene, seeds=seeds)
+    _run_to_paths(r, o)
+    hit_mats = o.out_camera_paths["rays"]["material"][:, 1][o.out_camera_paths["length"] > 1]
+    for m in (0, 8, 9):
+        assert (hit_mats == m).sum() > 50, m                          # every sphere is seen
+    for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
+        assert r.export_paths(which).tobytes() == ref.tobytes()
+    _run_rest(r, o)
+    assert r.export_aggregators()["total_contribution"].tobytes() == o.weight_aggregators["total_contribution"].tobytes()
+    r.run_samples(2); o.run_sample(); o.run_sample()
+    assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
+    np.testing.assert_allclose(r.read_accumulators()[0], o.summed_image, rtol=5e-5, atol=1e-8)
+
+
+def test_oblique_turntable_camera_and_odd_frame(oracle_mod):
+    """Camera not axis-aligned (turntable frame 1 of 8, scene.py:223-245) and a frame whose pixel
+    count is not a multiple of the workgroup size (101 x 57)."""
+    import clive2_amd as c2
+    scene = c2.create_scene_from_preset_with_params("empty", 101, 57, frame_idx=1, total_frames=8)
+    r, o = _pair(scene, oracle_mod)
+    r.make_light_rays(); o.make_light_rays(); r.make_camera_rays(); o.make_camera_rays()
+    assert r.export_rays(CAMERA).tobytes() == o.camera_ray_buffer.tobytes()
+    r.trace_light_rays(); o.trace_light_rays(); r.trace_camera_rays(); o.trace_camera_rays()
+    for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
+        assert r.export_paths(which).tobytes() == ref.tobytes()
+    _run_rest(r, o)
+    agg = r.export_aggregators()
+    for f in ("weights", "total_contribution", "contrib_weight_sum"):
+        assert agg[f].tobytes() == o.weight_aggregators[f].tobytes(), f
+    img = r.read_accumulators()[0]
+    np.testing.assert_allclose(img, o.summed_image, rtol=5e-5, atol=1e-8)
+    assert (o.out_light_image[:, :3] > 0).any()                  # light paths do project onto the oblique film
