@@ -11,8 +11,8 @@
  * PARITY STATUS: "parity unpinned by the reference" -- the reference ships no tests, golden
  * vectors or runnable device code.  The oracle is pinned instead by
  * (a) RNG known-answer vectors computed from trace.metal:87-93, (b) analytic cases
- * (tests/test_oracle_*.py), (c) an independent numpy restatement of the ray generators and
- * of traverse_bvh (oracle/np_kernels.py), (d) the reference's own BDPT-vs-unidirectional
+ * (tests/test_oracle_*.py), (c) an independent numpy restatement of the ray generators, the
+ * hemisphere samplers, detmath and traverse_bvh (oracle/np_kernels.py), (d) the reference's own BDPT-vs-unidirectional
  * self-consistency check.
  *
  * Pinned interpretation of Metal semantics (all float32, no FMA contraction):

@@ -3,6 +3,8 @@ float32) of three pieces of the reference's device code, used only to pin the C 
 
     xorshift_random        trace.metal:87-93
     generate_camera_rays   trace.metal:1020-1067   (K2)
+    generate_light_rays    trace.metal:1070-1124   (K1; with numpy statements of detmath sin/cos)
+    orthonormal, random_hemisphere_cosine / _uniform   trace.metal:200-224
     traverse_bvh           trace.metal:106-176     (closest hit, per-ray stack)
 
 Every operation is an IEEE binary32 numpy ufunc applied in the reference's order (numpy's
@@ -128,3 +130,122 @@ def traverse(origin, direction, boxes, triangles):
                     bu[rr] = u[ok]
                     bv[rr] = v[ok]
     return best_i, best_t, bu, bv
+
+
+# ---- detmath (oracle/detmath.h) restated with numpy float32 ufuncs, same operation order ----
+_FOPI, _DP1, _DP2, _DP3 = f32(1.27323954473516), f32(0.78515625), f32(2.4187564849853515625e-4), f32(3.77489497744594108e-8)
+_PIO2 = f32(1.5707963267948966192)
+
+
+def _sin_poly(x, z):
+    y = ((f32(-1.9515295891E-4) * z + f32(8.3321608736E-3)) * z - f32(1.6666654611E-1)) * z * x
+    return y + x
+
+
+def _cos_poly(z):
+    y = ((f32(2.443315711809948E-005) * z - f32(1.388731625493765E-003)) * z + f32(4.166664568298827E-002)) * z * z
+    y = y - f32(0.5) * z
+    return y + f32(1.0)
+
+
+def det_sincos(xx):
+    """(sin, cos) of float32 arrays in [0, 8192]: octant reduction + minimax polynomials."""
+    xx = np.asarray(xx, dtype=f32)
+    x = np.abs(xx)
+    j = (_FOPI * x).astype(np.int32)
+    y = j.astype(f32)
+    odd = (j & 1) == 1
+    j = np.where(odd, j + 1, j)
+    y = np.where(odd, y + f32(1.0), y).astype(f32)
+    j = j & 7
+    hi = j > 3
+    sneg = (xx < 0) ^ hi
+    cneg = hi.copy()
+    j = np.where(hi, j - 4, j)
+    cneg ^= (j > 1)
+    x = ((x - y * _DP1) - y * _DP2) - y * _DP3
+    z = x * x
+    ps, pc = _sin_poly(x, z), _cos_poly(z)
+    swap = (j == 1) | (j == 2)
+    s = np.where(swap, pc, ps)
+    c = np.where(swap, ps, pc)
+    return np.where(sneg, -s, s).astype(f32), np.where(cneg, -c, c).astype(f32)
+
+
+def det_asin(xx):
+    xx = np.asarray(xx, dtype=f32)
+    a = np.abs(xx)
+    big = a > f32(0.5)
+    zb = f32(0.5) * (f32(1.0) - a)
+    x = np.where(big, np.sqrt(zb), a).astype(f32)
+    z = np.where(big, zb, x * x).astype(f32)
+    p = ((((f32(4.2163199048E-2) * z + f32(2.4181311049E-2)) * z + f32(4.5470025998E-2)) * z + f32(7.4953002686E-2)) * z
+         + f32(1.6666752422E-1)) * z * x + x
+    p = np.where(big, _PIO2 - (p + p), p).astype(f32)
+    p = np.where(a < f32(1.0e-4), a, p)
+    return np.where(xx < 0, -p, p).astype(f32)
+
+
+def det_acos(x):
+    x = np.asarray(x, dtype=f32)
+    hi = x > f32(0.5)
+    lo = x < f32(-0.5)
+    r_hi = f32(2.0) * det_asin(np.sqrt(f32(0.5) * (f32(1.0) - np.where(hi, x, f32(1.0)))))
+    r_lo = f32(3.14159265358979323846) - f32(2.0) * det_asin(np.sqrt(f32(0.5) * (f32(1.0) + np.where(lo, x, f32(-1.0)))))
+    r_mid = _PIO2 - det_asin(np.where(hi | lo, f32(0.0), x))
+    return np.where(hi, r_hi, np.where(lo, r_lo, r_mid)).astype(f32)
+
+
+PI = f32(3.14159265359)
+
+
+def orthonormal(n):
+    ax, ay, az = np.abs(n[:, 0]), np.abs(n[:, 1]), np.abs(n[:, 2])
+    pick_x = (ax <= ay) & (ax <= az)
+    pick_y = ~pick_x & (ay <= az)
+    v = np.zeros_like(n)
+    v[pick_x, 0] = 1
+    v[pick_y, 1] = 1
+    v[~pick_x & ~pick_y, 2] = 1
+    x = _normalize(v - _dot(v, n)[:, None] * n)
+    y = _normalize(_cross(n, x))
+    return x, y
+
+
+def random_hemisphere_uniform(xa, ya, za, rx, ry):
+    z = rx
+    r = np.sqrt(_max(f32(0.0), f32(1.0) - z * z))
+    phi = (f32(2) * PI) * ry
+    sp, cp = det_sincos(phi)
+    return _normalize(((r * cp)[:, None] * xa + (r * sp)[:, None] * ya) + z[:, None] * za)
+
+
+def random_hemisphere_cosine(xa, ya, za, rx, ry):
+    theta = det_acos(np.sqrt(rx))
+    phi = (f32(2) * PI) * ry
+    st, ct = det_sincos(theta)
+    sp, cp = det_sincos(phi)
+    return _normalize(((st * cp)[:, None] * xa + (st * sp)[:, None] * ya) + ct[:, None] * za)
+
+
+def generate_light_rays(light_triangles, areas, seeds):
+    """K1.  Returns (origin, direction, l_importance, light_index, new_seeds)."""
+    count = len(light_triangles)
+    s0, s1 = seeds[:, 0].copy(), seeds[:, 1].copy()
+    s0, r = xorshift(s0)
+    li = np.minimum((r * f32(count)).astype(np.int32), count - 1)
+    s0, u = xorshift(s0)
+    s1, v = xorshift(s1)
+    flip = (u + v) > f32(1.0)
+    u = np.where(flip, f32(1.0) - u, u).astype(f32)
+    v = np.where(flip, f32(1.0) - v, v).astype(f32)
+    w = f32(1.0) - u - v
+    T = light_triangles[li]
+    n = T["normal"][:, :3].astype(f32)
+    origin = ((T["v0"][:, :3] * u[:, None] + T["v1"][:, :3] * v[:, None]) + T["v2"][:, :3] * w[:, None]) + DELTA * n
+    x, y = orthonormal(n)
+    s0, rx = xorshift(s0)
+    s1, ry = xorshift(s1)
+    d = random_hemisphere_uniform(x, y, n, rx, ry)
+    l_imp = f32(1.0) / (f32(count) * areas[li].astype(f32))
+    return origin.astype(f32), d.astype(f32), l_imp.astype(f32), li, np.stack([s0, s1], axis=1)

@@ -249,3 +249,43 @@ def test_zero_length_paths_are_defined(oracle_mod):
     o.join_paths()
     assert (o.weight_aggregators[5]["weights"] == 0).all()
     assert (o.weight_aggregators[5]["total_contribution"] == 0).all()
+
+
+def test_detmath_and_light_rays_match_numpy_restatement(oracle_mod):
+    """Second restatement of detmath sin/cos/acos and of K1 (orthonormal frame, uniform hemisphere)
+    in numpy float32 agrees with the C oracle bit for bit."""
+    from oracle import np_kernels as npk
+    x = np.linspace(0, 2 * np.pi, 200001).astype(np.float32)
+    s, c = npk.det_sincos(x)
+    assert s.tobytes() == oracle_mod.det_math("sin", x).tobytes()
+    assert c.tobytes() == oracle_mod.det_math("cos", x).tobytes()
+    y = np.linspace(0, 1, 100001).astype(np.float32)
+    assert npk.det_acos(y).tobytes() == oracle_mod.det_math("acos", y).tobytes()
+    scene = c2.create_scene_from_preset("empty", 80, 50)
+    o = oracle_mod.OracleRenderer(scene)
+    seeds0 = o.rand_buffer.copy()
+    o.make_light_rays()
+    org, d, l_imp, li, seeds1 = npk.generate_light_rays(scene.light_triangles, scene.light_surface_areas, seeds0)
+    assert o.light_ray_buffer["origin"][:, :3].tobytes() == org.tobytes()
+    assert o.light_ray_buffer["direction"][:, :3].tobytes() == d.tobytes()
+    assert o.light_ray_buffer["l_importance"].tobytes() == l_imp.tobytes()
+    assert np.array_equal(o.light_ray_buffer["triangle"], scene.light_triangle_indices[li])
+    assert np.array_equal(o.rand_buffer, seeds1)
+    # light rays leave the emitter downwards, from just below it (y = 9.5 - DELTA)
+    assert (d[:, 1] <= 0).all() and np.allclose(org[:, 1], 9.5 - 1e-4, atol=1e-6)
+    # cosine-hemisphere sampler of the diffuse bounce: unit vectors in the upper hemisphere of n
+    n = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (1000, 1))
+    xa, ya = npk.orthonormal(n)
+    rng = np.random.RandomState(1)
+    wo = npk.random_hemisphere_cosine(xa, ya, n, rng.rand(1000).astype(np.float32), rng.rand(1000).astype(np.float32))
+    assert np.allclose(np.linalg.norm(wo, axis=1), 1, atol=1e-6) and (wo[:, 2] >= 0).all()
+    # ... and it is the one the oracle's diffuse bounce uses
+    import ctypes as C
+    out = (C.c_float * 6)()
+    f3 = lambda a: (C.c_float * 3)(*a)
+    rr = rng.rand(50, 2).astype(np.float32)
+    ref = npk.random_hemisphere_cosine(xa[:50], ya[:50], n[:50], rr[:, 0].copy(), rr[:, 1].copy())
+    for k in range(50):
+        oracle_mod.lib().orc_bounce(0, f3([0.1, 0.2, 0.97]), f3([0, 0, 1]), f3([0, 0, 1]), C.c_float(1), C.c_float(1.5),
+                                    C.c_float(0), 1, C.c_float(float(rr[k, 0])), C.c_float(float(rr[k, 1])), out)
+        assert np.array(out[:3], np.float32).tobytes() == ref[k].tobytes()
