@@ -55,8 +55,9 @@ __device__ __forceinline__ float det_sinf(float x) { float s, c; det_sincosf(x, 
 __device__ __forceinline__ float det_cosf(float x) { float s, c; det_sincosf(x, s, c); return c; }
 
 __device__ __forceinline__ float det_asinf(float xx) {
-    float a = __builtin_fabsf(xx), x, z;
+    // |x| by comparison, not by clearing the sign bit: asin(-0) must stay -0 like the CPU statement
     bool neg = xx < 0.0f, flag = false;
+    float a = neg ? -xx : xx, x, z;
     if (!(a <= 1.0f)) return a - a + (a - a) / (a - a);
     if (a < 1.0e-4f) return neg ? -a : a;
     if (a > 0.5f) { z = 0.5f * (1.0f - a); x = __builtin_sqrtf(z); flag = true; }

@@ -636,6 +636,26 @@ __global__ void k_selftest_exact_math(unsigned long long* out) {
     if (bad_pi) atomicAdd(out + 1, bad_pi);
 }
 
+// Elementwise probe of the deterministic elementary functions (detmath.hpp) and of the exact
+// reciprocal: which = 0 sin, 1 cos, 2 acos, 3 atan, 4 exp, 5 asin, 6 rcp_exact, 7 div_pi.
+__global__ void k_probe_math(int which, size_t n, const float* __restrict__ in, float* __restrict__ out) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = in[i];
+        float y;
+        switch (which) {
+            case 0: y = det_sinf(x); break;
+            case 1: y = det_cosf(x); break;
+            case 2: y = det_acosf(x); break;
+            case 3: y = det_atanf(x); break;
+            case 4: y = det_expf(x); break;
+            case 5: y = det_asinf(x); break;
+            case 6: y = rcp_exact(x); break;
+            default: y = div_pi(x); break;
+        }
+        out[i] = y;
+    }
+}
+
 // ---------------------------------------------------------------- debug exports (reference AoS)
 struct RayRec {   // struct Ray, trace.metal:7-23
     float origin[4], direction[4], inv_direction[4], color[4], normal[4];

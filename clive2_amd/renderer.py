@@ -277,6 +277,14 @@ class Renderer:
                     "probe_traverse")
         return bi, bt, u, v
 
+    def probe_math(self, which, x):
+        """Device detmath / exact-reciprocal functions on a float32 array (`which`: sin cos acos atan exp asin rcp div_pi)."""
+        code = ["sin", "cos", "acos", "atan", "exp", "asin", "rcp", "div_pi"].index(which)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        self._check(self._L.cl2_probe_math(self._h, code, ptr(x), C.c_size_t(x.size), ptr(out)), "probe_math")
+        return out
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._L.cl2_destroy(self._h)

@@ -138,6 +138,10 @@ int cl2_reset_counters(cl2_renderer* r);
  * re-runs that proof on the device and returns the number of inputs that disagree (must be 0, 0). */
 int cl2_selftest_exact_math(cl2_renderer* r, uint64_t* rcp_mismatches, uint64_t* divpi_mismatches);
 
+/* Elementwise probe of the device's deterministic elementary functions: which = 0 sin, 1 cos, 2 acos,
+ * 3 atan, 4 exp, 5 asin (csrc/detmath.hpp), 6 rcp_exact, 7 div_pi (csrc/vecmath.hpp).  Host arrays. */
+int cl2_probe_math(cl2_renderer* r, int which, const float* in, size_t n, float* out);
+
 /* -- debug exports in the reference's AoS layouts (stage-level parity) -- */
 int cl2_export_rays(cl2_renderer* r, int which, void* out_rays, size_t n_records);        /* Ray[batch]  */
 int cl2_export_paths(cl2_renderer* r, int which, void* out_paths, size_t n_records);      /* Path[batch] */

@@ -1005,6 +1005,7 @@ void orc_traverse(int n, const Ray *rays, const Box *boxes, const Triangle *tria
 }
 
 void orc_math(int which, int n, const float *in, float *out) {
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < n; i++) {
         float x = in[i];
         switch (which) {

@@ -279,3 +279,37 @@ def test_oblique_turntable_camera_and_odd_frame(oracle_mod):
     img = r.read_accumulators()[0]
     np.testing.assert_allclose(img, o.summed_image, rtol=5e-5, atol=1e-8)
     assert (o.out_light_image[:, :3] > 0).any()                  # light paths do project onto the oblique film
+
+
+def test_device_detmath_equals_oracle_detmath(cornell_small, oracle_mod):
+    """csrc/detmath.hpp vs oracle/detmath.h on ~1e7 inputs per function: every 97th binary32 value of
+    the ranges the tracer uses, plus specials.  Bitwise equal (NaNs compared as NaNs)."""
+    from clive2_amd.renderer import Renderer
+    r = Renderer(cornell_small)
+
+    def floats_between(lo, hi, stride):
+        a, b = np.float32(lo).view(np.uint32), np.float32(hi).view(np.uint32)
+        return np.arange(int(a), int(b) + 1, stride, dtype=np.uint64).astype(np.uint32).view(np.float32)
+
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, 1e-38, 3.4e38, 0.5, 2.414213562373095, 88.0, -87.0],
+                       dtype=np.float32)
+    cases = {
+        "sin": np.concatenate([floats_between(0.0, 6.2831855, 97), -floats_between(1e-3, 6.2831855, 977), special]),
+        "cos": np.concatenate([floats_between(0.0, 6.2831855, 97), -floats_between(1e-3, 6.2831855, 977), special]),
+        "acos": np.concatenate([floats_between(0.0, 1.0, 97), -floats_between(1e-6, 1.0, 977), special]),
+        "asin": np.concatenate([floats_between(0.0, 1.0, 97), special]),
+        "atan": np.concatenate([floats_between(0.0, 1e6, 197), -floats_between(1e-6, 100.0, 977), special]),
+        "exp": np.concatenate([-floats_between(1e-8, 90.0, 97), floats_between(0.0, 10.0, 977), special]),
+    }
+    for name, x in cases.items():
+        got, ref = r.probe_math(name, x), oracle_mod.det_math(name, x)
+        same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+        assert same.all(), (name, x[~same][:5], got[~same][:5], ref[~same][:5])
+        assert len(x) > 1_000_000
+    # the exact reciprocal / x-over-pi against numpy's IEEE division
+    x = np.concatenate([floats_between(1e-30, 1e30, 389), -floats_between(1e-30, 1e30, 3889), special])
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore", under="ignore"):
+        for name, ref in (("rcp", np.float32(1.0) / x), ("div_pi", x / np.float32(3.14159265359))):
+            got = r.probe_math(name, x)
+            same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+            assert same.all(), name
