@@ -47,7 +47,7 @@ EXPORTS = [
     "cl2_read_accumulators_packed", "cl2_write_accumulators_packed", "cl2_copy_accumulators_to_device",
     "cl2_copy_accumulators_from_device", "cl2_set_profiling", "cl2_set_counting", "cl2_set_debug_flags", "cl2_read_counters",
     "cl2_reset_counters", "cl2_selftest_exact_math", "cl2_export_rays", "cl2_export_paths", "cl2_export_aggregators",
-    "cl2_export_sample_images", "cl2_probe_traverse", "cl2_probe_math",
+    "cl2_export_sample_images", "cl2_probe_traverse", "cl2_probe_math", "cl2_probe_bounce",
 ]
 
 

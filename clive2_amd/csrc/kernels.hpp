@@ -656,6 +656,28 @@ __global__ void k_probe_math(int which, size_t n, const float* __restrict__ in, 
     }
 }
 
+// Elementwise probe of the bounce routines (bsdf.hpp).  in: 12 floats per item {wi.xyz, n.xyz, rx, ry,
+// ni, no, alpha, kind} with kind 0 diffuse, 1 reflect, 2 transmit, 3 GGX_sample (the microfacet normal m is
+// GGX_sample(n, rx, ry, alpha) in every case, as in generate_paths); out: 8 floats {wo.xyz, f, c_p, l_p,
+// fresnel(wi,m), m.x}.  `from_camera` selects the pdf direction convention.
+__global__ void k_probe_bounce(size_t n, int from_camera, const float* __restrict__ in, float* __restrict__ out) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float* p = in + 12 * i;
+        const V3 wi = v3(p[0], p[1], p[2]), nn = v3(p[3], p[4], p[5]);
+        const float rx = p[6], ry = p[7], ni = p[8], no = p[9], alpha = p[10];
+        const int kind = (int)p[11];
+        const V3 m = GGX_sample(nn, rx, ry, alpha);
+        Bounce b{v3(0, 0, 0), 1.0f, 1.0f, 1.0f};
+        if (kind == 0) b = diffuse_bounce(wi, nn, from_camera != 0, rx, ry);
+        else if (kind == 1) b = reflect_bounce(wi, nn, m, ni, no, alpha, from_camera != 0);
+        else if (kind == 2) b = transmit_bounce(wi, nn, m, ni, no, alpha, from_camera != 0);
+        else b.wo = m;
+        float* q = out + 8 * i;
+        q[0] = b.wo.x; q[1] = b.wo.y; q[2] = b.wo.z; q[3] = b.f; q[4] = b.c_p; q[5] = b.l_p;
+        q[6] = degreve_fresnel(wi, m, ni, no); q[7] = m.x;
+    }
+}
+
 // ---------------------------------------------------------------- debug exports (reference AoS)
 struct RayRec {   // struct Ray, trace.metal:7-23
     float origin[4], direction[4], inv_direction[4], color[4], normal[4];

@@ -680,6 +680,22 @@ int cl2_probe_math(cl2_renderer* r, int which, const float* in, size_t n, float*
     dev_free(r, d_in); dev_free(r, d_out);
     return rc;
 }
+int cl2_probe_bounce(cl2_renderer* r, int from_camera, const float* in, size_t n, float* out) {
+    if (!r || !in || !out) return CL2_E_INVALID;
+    if (n == 0) return CL2_OK;
+    HIP_TRY(r, hipSetDevice(r->device));
+    float *d_in = nullptr, *d_out = nullptr;
+    int rc = dev_alloc(r, &d_in, 12 * n);
+    if (rc == CL2_OK) rc = dev_alloc(r, &d_out, 8 * n);
+    if (rc == CL2_OK && hipMemcpy(d_in, in, 12 * n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = fail(r, CL2_E_HIP, "probe upload failed");
+    if (rc == CL2_OK) {
+        hipLaunchKernelGGL(k_probe_bounce, dim3(1024), dim3(BLOCK), 0, r->stream, n, from_camera, d_in, d_out);
+        rc = drain(r);
+    }
+    if (rc == CL2_OK && hipMemcpy(out, d_out, 8 * n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(r, CL2_E_HIP, "probe download failed");
+    dev_free(r, d_in); dev_free(r, d_out);
+    return rc;
+}
 int cl2_set_traversal_mode(cl2_renderer* r, int mode) {
     if (!r) return CL2_E_INVALID;
     if (mode < 0 || mode > 2) return fail(r, CL2_E_INVALID, "traversal mode must be 0 (auto), 1 (fused) or 2 (split)");

@@ -285,6 +285,14 @@ class Renderer:
         self._check(self._L.cl2_probe_math(self._h, code, ptr(x), C.c_size_t(x.size), ptr(out)), "probe_math")
         return out
 
+    def probe_bounce(self, items, from_camera=True):
+        """Device bounce routines on an (n,12) float32 array {wi, n, rx, ry, ni, no, alpha, kind} -> (n,8)."""
+        items = np.ascontiguousarray(items, dtype=np.float32).reshape(-1, 12)
+        out = np.empty((len(items), 8), np.float32)
+        self._check(self._L.cl2_probe_bounce(self._h, int(bool(from_camera)), ptr(items), C.c_size_t(len(items)), ptr(out)),
+                    "probe_bounce")
+        return out
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._L.cl2_destroy(self._h)

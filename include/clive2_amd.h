@@ -141,6 +141,10 @@ int cl2_selftest_exact_math(cl2_renderer* r, uint64_t* rcp_mismatches, uint64_t*
 /* Elementwise probe of the device's deterministic elementary functions: which = 0 sin, 1 cos, 2 acos,
  * 3 atan, 4 exp, 5 asin (csrc/detmath.hpp), 6 rcp_exact, 7 div_pi (csrc/vecmath.hpp).  Host arrays. */
 int cl2_probe_math(cl2_renderer* r, int which, const float* in, size_t n, float* out);
+/* Elementwise probe of the bounce routines (src/trace.metal:226-233, :254-264, :334-379).  in: 12 floats per
+ * item {wi.xyz, n.xyz, rx, ry, ni, no, alpha, kind}, kind 0 diffuse / 1 reflect / 2 transmit / 3 GGX_sample
+ * only; out: 8 floats {wo.xyz, f, c_p, l_p, fresnel(wi,m), m.x} with m = GGX_sample(n, rx, ry, alpha). */
+int cl2_probe_bounce(cl2_renderer* r, int from_camera, const float* in, size_t n, float* out);
 
 /* -- debug exports in the reference's AoS layouts (stage-level parity) -- */
 int cl2_export_rays(cl2_renderer* r, int which, void* out_rays, size_t n_records);        /* Ray[batch]  */

@@ -1041,3 +1041,25 @@ void orc_bounce(int kind, const float *wi, const float *n, const float *m, float
     else transmit_bounce(WI, N, M, ni, no, alpha, from_camera, &wo, &f, &c_p, &l_p);
     out[0] = wo.x; out[1] = wo.y; out[2] = wo.z; out[3] = f; out[4] = c_p; out[5] = l_p;
 }
+
+/* Batch form of the bounce probe, same item layout as the product's cl2_probe_bounce:
+ * in 12 floats {wi.xyz, n.xyz, rx, ry, ni, no, alpha, kind}; out 8 floats {wo.xyz, f, c_p, l_p, fresnel, m.x}. */
+void orc_bounce_batch(int n, int from_camera, const float *in, float *out) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) {
+        const float *p = in + 12 * i;
+        f3 wi = V3(p[0], p[1], p[2]), nn = V3(p[3], p[4], p[5]);
+        float rx = p[6], ry = p[7], ni = p[8], no = p[9], alpha = p[10];
+        int kind = (int)p[11];
+        f3 m = GGX_sample(nn, rx, ry, alpha);
+        f3 wo = V3(0, 0, 0);
+        float f = 1.0f, c_p = 1.0f, l_p = 1.0f;
+        if (kind == 0) diffuse_bounce(wi, nn, from_camera, rx, ry, &wo, &f, &c_p, &l_p);
+        else if (kind == 1) reflect_bounce(wi, nn, m, ni, no, alpha, from_camera, &wo, &f, &c_p, &l_p);
+        else if (kind == 2) transmit_bounce(wi, nn, m, ni, no, alpha, from_camera, &wo, &f, &c_p, &l_p);
+        else wo = m;
+        float *q = out + 8 * i;
+        q[0] = wo.x; q[1] = wo.y; q[2] = wo.z; q[3] = f; q[4] = c_p; q[5] = l_p;
+        q[6] = degreve_fresnel(wi, m, ni, no); q[7] = m.x;
+    }
+}
