@@ -160,7 +160,7 @@ def main():
     r.reduce_accumulators()          # untimed: creates the RCCL communicator and its buffers before the clock starts
     r.reset_counters()
     r.reset_accumulators()
-    r.set_profiling(1)               # timed region: HIP events around the traversal launches only
+    r.set_profiling(1)               # timed region: HIP events around the connection-ray traversal launch only
     if args.debug_flags:
         r.set_debug_flags(args.debug_flags)
 
@@ -194,16 +194,15 @@ def main():
         assert np.isfinite(img).all() and (cnt >= args.steps * world).all(), "accumulators corrupt"
         b_ray = 48.0 + 32.0 * n_node + 36.0 * n_tri
         stages = {k[3:]: round(cb[k] / n_break, 4) for k in cb if k.startswith("ms_")}
-        # dominant traversal kernel: the connection-ray launch (one per sample)
+        # the roofline kernel: the connection-ray traversal launch (70 % of all rays, one launch per
+        # sample), timed with HIP events on the renderer's stream inside the timed region
         k_ms, k_rays, k_launches = c["ms_traverse_conn"], c["rays_traverse_conn"], c["launches_traverse_conn"]
-        k_name = "k_traverse_conn"
-        if c["ms_traverse_paths"] > k_ms:
-            k_ms, k_rays, k_launches, k_name = (c["ms_traverse_paths"], c["rays_traverse_paths"],
-                                                c["launches_traverse_paths"], "k_traverse_paths")
+        k_name = "k_traverse_conn" if args.traversal_mode == 1 or (args.traversal_mode == 0 and args.scene == "cornell") \
+            else "k_traverse_persistent<ConnRaySource>"
         achieved = (k_rays * b_ray) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_src = measured_traffic(k_name) if args.scene == "cornell" and (W, H) == (1920, 1080) else (None, None)
         out = {
-            "metric": "Mrays/sec (whole job), 1080p Cornell box BDPT",
+            "metric": "Mrays/sec (whole node) + HBM GB/s, 1080p Cornell box, 1/2/4/8 MI355X",
             "value": round(rays_total / dt / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -214,6 +213,8 @@ def main():
                                    f"{args.steps} spp per GPU", "width": W, "height": H,
                        "rays_per_pixel_sample": round(rays_local / (args.steps * W * H), 3),
                        "parallelism": f"sample-split x{world}, one {'RCCL' if backend == 'nccl' else backend} all-reduce of the accumulators"},
+            "hbm_gbs": {"kernel": k_name, "algorithmic": round(achieved, 1),
+                        "measured_pmc": round(traffic / (k_ms / max(k_launches, 1) * 1e-3) / 1e9, 1) if traffic else None},
             "roofline": {"bound": "hbm", "kernel": k_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_ray": round(b_ray, 1), "n_node": round(n_node, 3), "n_tri": round(n_tri, 3),

@@ -45,7 +45,7 @@ struct cl2_renderer {
     hipStream_t stream = nullptr;
     std::string err;
     bool scene_ok = false, counting = false;
-    int profiling = 0;                   // 0 off, 1 traversal launches only, 2 every stage
+    int profiling = 0;                   // 0 off, 1 the connection-ray traversal launch only, 2 every stage
     int debug_flags = 0;
     int traversal_mode = 0;              // 0 auto, 1 fused (one ray per lane), 2 split (persistent traversal + ray replacement)
     unsigned* d_work = nullptr;          // [8] work counters of the persistent traversal launches
@@ -129,7 +129,7 @@ hipEvent_t take_event(cl2_renderer* r) {
 struct Timed {   // records a HIP-event span around a launch when profiling is on
     cl2_renderer* r; int stage; hipEvent_t a = nullptr;
     Timed(cl2_renderer* r_, int st) : r(r_), stage(st) {
-        const bool wanted = r->profiling >= 2 || (r->profiling == 1 && (st == ST_TRAVERSE_CONN || st == ST_TRAVERSE_PATHS));
+        const bool wanted = r->profiling >= 2 || (r->profiling == 1 && st == ST_TRAVERSE_CONN);
         if (wanted) { a = take_event(r); (void)hipEventRecord(a, r->stream); }
     }
     ~Timed() {

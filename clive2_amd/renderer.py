@@ -212,7 +212,7 @@ class Renderer:
 
     # ---- counters / profiling ----
     def set_profiling(self, level=2):
-        """HIP-event stage timers: 0 off, 1 the traversal launches only, 2 (or True) every stage."""
+        """HIP-event stage timers: 0 off, 1 the connection-ray traversal launch only, 2 (or True) every stage."""
         level = 2 if level is True else int(level)
         self._check(self._L.cl2_set_profiling(self._h, level), "set_profiling")
 

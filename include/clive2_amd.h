@@ -124,7 +124,7 @@ int cl2_copy_accumulators_to_device(cl2_renderer* r, void* device_dst, size_t n_
 int cl2_copy_accumulators_from_device(cl2_renderer* r, const void* device_src, size_t n_floats);
 
 /* -- counters / profiling -- */
-int cl2_set_profiling(cl2_renderer* r, int level);  /* HIP-event timers: 0 off, 1 traversal launches only, 2 every stage */
+int cl2_set_profiling(cl2_renderer* r, int level);  /* HIP-event timers: 0 off, 1 the connection-ray traversal launch only, 2 every stage */
 int cl2_set_counting(cl2_renderer* r, int on);      /* node / triangle test tallies in the traversal kernels */
 int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
 /* performance-experiment switches; results are NOT valid renders when any bit is set.
