@@ -1,0 +1,85 @@
+"""Differential fuzzing: random scenes (camera pose, meshes, materials, frame size, launch organisation)
+rendered by the HIP path and by the oracle; subpaths, RNG state and filter aggregators must match bit for
+bit, the accumulated image to 5e-5.   python tools/fuzz_parity.py [n_scenes] [first_seed]"""
+import os
+import sys
+import time
+
+os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))   # the oracle is OpenMP code
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+sys.path.insert(0, ".")
+import numpy as np
+
+import clive2_amd as c2
+from clive2_amd import struct_types as st
+from clive2_amd.load import get_materials
+from clive2_amd.meshes import icosphere, noisy_blob
+from clive2_amd.renderer import Renderer, make_seeds
+from oracle import oracle as orc
+
+
+def random_scene(rng):
+    w, h = int(rng.randint(17, 120)), int(rng.randint(11, 80))
+    mats = np.zeros(12, dtype=st.Material)
+    mats[:8] = get_materials()
+    for m in range(8, 12):
+        mats[m] = mats[rng.randint(0, 6)]
+        mats["type"][m] = rng.randint(0, 4)
+        mats["alpha"][m] = rng.choice([0.0, 0.02, 0.2, 0.8])
+        mats["ior"][m] = rng.choice([1.1, 1.5, 2.4])
+    mats["alpha"][5] = rng.choice([0.0, 0.1])
+    specs = []
+    for _ in range(rng.randint(0, 4)):
+        sub = int(rng.randint(0, 4))
+        mesh = icosphere(sub, radius=float(rng.uniform(0.5, 2.5))) if rng.rand() < 0.7 else noisy_blob(sub, radius=float(rng.uniform(0.8, 2.0)), center=(0, 0, 0), seed=int(rng.randint(1 << 30)))
+        specs.append(dict(mesh=mesh, material=int(rng.choice([0, 1, 4, 5, 8, 9, 10, 11])),
+                          offset=np.array([rng.uniform(-6, 6), rng.uniform(-1, 6), rng.uniform(-7, 3)])))
+    theta = rng.uniform(0, 2 * np.pi) if rng.rand() < 0.5 else 0.0
+    center = np.array([np.sin(theta) * 7.0, rng.uniform(0.0, 5.0), np.cos(theta) * 7.0])
+    direction = np.array([-np.sin(theta), rng.choice([0.0, 0.0, -0.2, 0.15]), -np.cos(theta)])
+    direction = direction / np.linalg.norm(direction)
+    builder = rng.choice(["numpy", "native"])
+    return c2.create_scene(w, h, center, direction, file_specs=specs, materials=mats, bvh_builder=str(builder)), (w, h, len(specs), builder)
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    orc.build()
+    bad = 0
+    for k in range(first, first + n):
+        rng = np.random.RandomState(1000 + k)
+        scene, desc = random_scene(rng)
+        B = scene.pixel_width * scene.pixel_height
+        seeds = make_seeds(B, seed=k)
+        r, o = Renderer(scene, seeds=seeds), orc.OracleRenderer(scene, seeds=seeds)
+        mode, levels = int(rng.randint(0, 3)), int(rng.randint(1, 7))
+        r.set_traversal_mode(mode)
+        r.set_levels_per_launch(levels)
+        t0 = time.time()
+        ok = True
+        for x in (r, o):
+            x.make_light_rays(); x.make_camera_rays(); x.trace_light_rays(); x.trace_camera_rays()
+        ok &= r.export_paths(0).tobytes() == o.out_light_paths.tobytes()
+        ok &= r.export_paths(1).tobytes() == o.out_camera_paths.tobytes()
+        for x in (r, o):
+            x.join_paths(); x.finalize_samples(); x.gather_light_image(); x.process_images()
+        agg = r.export_aggregators()
+        ok &= agg["total_contribution"].tobytes() == o.weight_aggregators["total_contribution"].tobytes()
+        ok &= agg["weights"].tobytes() == o.weight_aggregators["weights"].tobytes()
+        r.run_samples(2); o.run_sample(); o.run_sample()
+        ok &= bool(np.array_equal(r.get_random_buffer(), o.rand_buffer))
+        img = r.read_accumulators()[0]
+        ok &= bool(np.allclose(img, o.summed_image, rtol=5e-5, atol=1e-8))
+        ok &= r.counters()["rays"] == o.rays_traced
+        print(f"scene {k}: {desc} tris={len(scene.triangles)} mode={mode} levels={levels} "
+              f"len_c={o.out_camera_paths['length'].mean():.2f} {'OK' if ok else 'MISMATCH'} ({time.time() - t0:.1f}s)", flush=True)
+        bad += not ok
+        r.close()
+    print(f"RESULT: {n - bad}/{n} scenes match")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
