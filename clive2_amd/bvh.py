@@ -64,8 +64,13 @@ class FastTreeBox:
     def __add__(self, other):
         if not isinstance(other, FastTreeBox):
             raise TypeError("Can only add another FastTreeBox")
-        return FastTreeBox(*(np.concatenate((getattr(self, f), getattr(other, f)), axis=0)
-                             for f in _FIELDS))
+        return FastTreeBox.concat([self, other])
+
+    @classmethod
+    def concat(cls, soups):
+        """One concatenation for many soups (pairwise `a + b + c ...` copies the growing arrays every
+        time: 10 s for the 49 meshes of the 1M-triangle scene).  Same result as the chained sum."""
+        return cls(*(np.concatenate([getattr(s, f) for s in soups], axis=0) for f in _FIELDS))
 
 
 def surface_areas(mins, maxes):

@@ -58,20 +58,20 @@ def create_scene(pixel_width=1280, pixel_height=720, cam_center=ZERO_VECTOR, cam
                  file_specs=None, materials=None, verbose=False, bvh_builder="auto"):
     camera = Camera(center=cam_center, direction=cam_direction, pixel_width=pixel_width,
                     pixel_height=pixel_height, phys_width=pixel_width / pixel_height, phys_height=1)
-    soup = FastTreeBox.from_triangle_objects(camera_geometry(camera) + triangles_for_box())
+    soups = [FastTreeBox.from_triangle_objects(camera_geometry(camera) + triangles_for_box())]
     for spec in file_specs or ():
         kw = dict(material=spec.get("material", 0), scale=spec.get("scale", 1.0),
                   offset=spec.get("offset", ZERO_VECTOR))
         if "mesh" in spec:
             v, f = spec["mesh"]
-            soup = soup + fast_load(np.asarray(v) * kw["scale"] + kw["offset"], np.asarray(f),
-                                    material=kw["material"])
+            soups.append(fast_load(np.asarray(v) * kw["scale"] + kw["offset"], np.asarray(f), material=kw["material"]))
         elif spec["file_path"].endswith(".ply"):
-            soup = soup + fast_load_ply(ply_path=spec["file_path"], **kw)
+            soups.append(fast_load_ply(ply_path=spec["file_path"], **kw))
         elif spec["file_path"].endswith(".obj"):
-            soup = soup + fast_load_obj(obj_path=spec["file_path"], **kw)
+            soups.append(fast_load_obj(obj_path=spec["file_path"], **kw))
         else:
             raise NotImplementedError(spec["file_path"])
+    soup = FastTreeBox.concat(soups) if len(soups) > 1 else soups[0]
 
     t0 = time.time()
     boxes, tris = np_flatten_bvh(construct_BVH(soup, builder=bvh_builder))
