@@ -44,7 +44,9 @@ enum { CL2_LIGHT = 0, CL2_CAMERA = 1 };
 /* Stage timers and tallies accumulated since cl2_reset_counters (replaces the reference's
  * `@timed` prints, src/constants.py:39-49).  One "ray" = one closest-hit BVH query =
  * one call of traverse_bvh (src/trace.metal:144).  Times are GPU milliseconds measured
- * with HIP events on the renderer's stream; they are only collected while profiling is on. */
+ * with HIP events on the renderer's stream; they are only collected while profiling is on.
+ * ms_traverse_paths = the subpath launches (closest hit + bounce per level; in the large-scene
+ * organisation: the persistent traversal launches, with their bounce launches under ms_bounce). */
 typedef struct {
     uint64_t rays;            /* all closest-hit queries */
     uint64_t conn_rays;       /* the subset issued by the connection stage */
