@@ -1063,3 +1063,50 @@ void orc_bounce_batch(int n, int from_camera, const float *in, float *out) {
         q[6] = degreve_fresnel(wi, m, ni, no); q[7] = m.x;
     }
 }
+
+/* ---- research probe (not part of the restatement): a front-to-back walk over the same tree, to
+ * measure what ordering would save and how often it disagrees with the reference's walk.  Children
+ * are entered nearest-first; everything else (tests, strict `<`, leaf order) as in traverse_bvh. ---- */
+void orc_traverse_ordered(int n, const Ray *rays, const Box *boxes, const Triangle *triangles,
+                          int32_t *best_i_out, float *best_t_out, Counters *counters) {
+#pragma omp parallel
+    {
+        Counters local = {0, 0, 0};
+#pragma omp for schedule(dynamic, 256)
+        for (int id = 0; id < n; id++) {
+            const Ray *ray = &rays[id];
+            int stack[128]; float tstack[128];
+            int sp = 0, best_i = -1;
+            float best_t = INFINITY, u, v;
+            local.rays++;
+            float t0 = INFINITY;
+            local.box_tests++;
+            if (ray_box_intersect(ray, &boxes[0], &t0)) { stack[sp] = 0; tstack[sp++] = t0; }
+            while (sp > 0) {
+                int node = stack[--sp];
+                float tn = tstack[sp];
+                if (!(tn < best_t)) continue;
+                const Box *b = &boxes[node];
+                if (b->right == 0) {
+                    float tl = INFINITY, tr = INFINITY;
+                    local.box_tests += 2;
+                    int hl = ray_box_intersect(ray, &boxes[b->left], &tl) && tl < best_t;
+                    int hr = ray_box_intersect(ray, &boxes[b->left + 1], &tr) && tr < best_t;
+                    if (hl && hr) {
+                        if (tl <= tr) { stack[sp] = b->left + 1; tstack[sp++] = tr; stack[sp] = b->left; tstack[sp++] = tl; }
+                        else { stack[sp] = b->left; tstack[sp++] = tl; stack[sp] = b->left + 1; tstack[sp++] = tr; }
+                    } else if (hl) { stack[sp] = b->left; tstack[sp++] = tl; }
+                    else if (hr) { stack[sp] = b->left + 1; tstack[sp++] = tr; }
+                } else {
+                    for (int i = b->left; i < b->right; i++) {
+                        float t = INFINITY;
+                        local.tri_tests++;
+                        if (ray_triangle_intersect(ray, &triangles[i], &t, &u, &v) && t < best_t) { best_i = i; best_t = t; }
+                    }
+                }
+            }
+            best_i_out[id] = best_i; best_t_out[id] = best_t;
+        }
+        counters_merge(counters, &local);
+    }
+}
