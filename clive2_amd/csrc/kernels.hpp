@@ -256,7 +256,7 @@ struct ShadeLds {
 };
 
 template <bool FROM_CAMERA, bool COUNT, bool EXT_HIT>
-__global__ __launch_bounds__(BLOCK) void k_trace_subpath(
+__global__ __launch_bounds__(BLOCK, 6) void k_trace_subpath(
         BvhView bvh, Stats* stats, int first, int end, const int* __restrict__ queue_in,
         const unsigned* __restrict__ count_in, int* __restrict__ queue_out, unsigned* __restrict__ count_out, int B,
         PathBufs pb, uint2* __restrict__ seeds, const float4* __restrict__ tri_shade_g,
@@ -463,7 +463,7 @@ __device__ __forceinline__ bool conn_ray(int t, const ConnVtx& lv, const ConnVtx
 // {slot, pixel}.  Tags are ordered wave-by-wave, slot-major inside a wave, so consecutive queue
 // entries are the same (t,s) strategy of neighbouring pixels: the vertex gathers of
 // k_traverse_conn are coalesced and its rays coherent.
-__global__ __launch_bounds__(BLOCK) void k_connect_setup(
+__global__ __launch_bounds__(BLOCK, 6) void k_connect_setup(
         int B, PathBufs lp, PathBufs cp, const MaterialDev* __restrict__ mats, CameraRec cam,
         int* __restrict__ ctag, unsigned* __restrict__ ccount, unsigned long long* __restrict__ cmask) {
     __shared__ unsigned s_wave_total[WAVES_PER_BLOCK];
