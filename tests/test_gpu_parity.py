@@ -345,3 +345,15 @@ def test_device_bounce_routines_equal_oracle(from_camera, cornell_small, oracle_
     bad = np.flatnonzero(~same.all(axis=1))
     assert len(bad) == 0, (len(bad), items[bad[:3]], got[bad[:3]], ref[bad[:3]])
     assert np.isfinite(ref[:, 3]).mean() > 0.9 and (ref[items[:, 11] == 2, 3] != 0).mean() > 0.3
+
+
+def test_render_cli_writes_an_image(tmp_path):
+    """The reference's command-line surface (render.py:13-19) on top of the HIP path."""
+    from clive2_amd import render
+    out = tmp_path / "cornell.png"
+    assert render.main(["--scene", "empty", "--width", "64", "--height", "36", "--samples", "3", "--out", str(out)]) == 0
+    from PIL import Image
+    img = np.asarray(Image.open(out))
+    assert img.shape == (36, 64, 3) and img.std() > 1          # a picture, not a constant
+    with pytest.raises(ValueError):
+        render.main(["--scene", "no-such-preset", "--width", "8", "--height", "8", "--samples", "1"])
