@@ -207,40 +207,13 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
     const V3 focal = cam3(cam.focal_point), cam_dir = cam3(cam.direction);
     const bool spec7 = __float_as_int(mats[7].color_type.w) > 0;
 
-    // ---- camera subpath: per-path tables to LDS.  All loads are issued before the first use (one
-    // memory round trip instead of one per vertex); done first so the registers are free again
-    // before the light subpath moves in. ----
+    // ---- camera subpath: its per-path tables (GC, RC, specular bits) are built incrementally inside the
+    // t loop below from the vertex that iteration loads anyway -- pair (t,s) only needs GC[0..t-2],
+    // RC[0..t-2] and the specular bits of camera[0..t-1] -- so the camera subpath is read once. ----
     unsigned c_spec = 0;
-    int first_light_hit = 0;                         // first camera vertex v >= 1 with hit_light (0 = none)
-    {
-        float4 ca[MAX_VERTS], cb[MAX_VERTS], cc[MAX_VERTS];
-#pragma unroll
-        for (int v = 0; v < MAX_VERTS; v++) {
-            const size_t k = (size_t)(v < Lc ? v : 0) * B + pid;      // clamp: always a valid address
-            ca[v] = cp.P0[k]; cb[v] = cp.P1[k]; cc[v] = cp.P2[k];
-        }
-        V3 prev_o = v3(0, 0, 0);
-        float prev_cos = 0.0f, prev_l = 0.0f, prev_c = 0.0f, prev_G = 0.0f;
-#pragma unroll
-        for (int v = 0; v < MAX_VERTS; v++) {
-            if (v < Lc) {
-                const float4 a = ca[v], b = cb[v], c = cc[v];
-                const float cosv = __builtin_fabsf(dot(v3(b), v3(c)));
-                const int meta = __float_as_int(c.w);
-                if (__float_as_int(mats[meta & 0xFF].color_type.w) > 0) c_spec |= 1u << v;
-                if (v > 0 && first_light_hit == 0 && (meta & META_HIT_LIGHT)) first_light_hit = v;
-                if (v > 0) {
-                    const float G = geom_term(prev_cos, cosv, prev_o, v3(a));          // GC[v-1]
-                    GCs[(v - 1) * BLOCK + tid] = G;
-                    // ratio of camera vertex m = v-1 once its far neighbour (v) is known
-                    const int m = v - 1;
-                    RCs[m * BLOCK + tid] = (m == 0) ? (prev_l * G) / prev_c : (prev_l * G) / (prev_c * prev_G);
-                    prev_G = G;
-                }
-                prev_o = v3(a); prev_cos = cosv; prev_l = b.w; prev_c = a.w;
-            }
-        }
-    }
+    bool light_hit_seen = false;                     // a camera vertex v >= 1 with hit_light was met
+    V3 cam_prev_o = v3(0, 0, 0);
+    float cam_prev_cos = 0.0f, cam_prev_l = 0.0f, cam_prev_c = 0.0f, cam_prev_G = 0.0f;
 
     // ---- light subpath -> registers; adjacent geometry terms and interior ratios ----
     LightVtx lv[MAX_VERTS];
@@ -287,9 +260,23 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
         const float c_cos = __builtin_fabsf(dot(v3(cP1), c_n));
         V3 prior_camera_color = v3(0, 0, 0);
         if (t >= 2) prior_camera_color = v3(cp.P3[ck - B]);
+        // per-path camera tables, vertex v = t-1 (same statements as the light side above)
+        {
+            const int v = t - 1;
+            if (__float_as_int(mats[c_meta & 0xFF].color_type.w) > 0) c_spec |= 1u << v;
+            if (v > 0) {
+                const float G = geom_term(cam_prev_cos, c_cos, cam_prev_o, c_o);           // GC[v-1]
+                GCs[(v - 1) * BLOCK + tid] = G;
+                const int m = v - 1;                       // ratio of camera vertex m, its far neighbour now known
+                RCs[m * BLOCK + tid] = (m == 0) ? (cam_prev_l * G) / cam_prev_c : (cam_prev_l * G) / (cam_prev_c * cam_prev_G);
+                cam_prev_G = G;
+            }
+            cam_prev_o = c_o; cam_prev_cos = c_cos; cam_prev_l = cP1.w; cam_prev_c = cP0.w;
+        }
         // unidirectional estimate of generate_paths (camera pass), trace.metal:523-528: first stored
-        // vertex v with hit_light -> rays[v-1].color / rays[v].tot_importance; both are this iteration's loads
-        if (t - 1 == first_light_hit && first_light_hit > 0) {
+        // vertex v >= 1 with hit_light -> rays[v-1].color / rays[v].tot_importance; both are this iteration's loads
+        if (t >= 2 && !light_hit_seen && (c_meta & META_HIT_LIGHT)) {
+            light_hit_seen = true;
             const V3 c = prior_camera_color / cP3.w;
             uni = make_float4(c.x, c.y, c.z, 1.0f);
         }
