@@ -74,6 +74,29 @@ def build(force=False, verbose=False):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel ships its own `libamdhip64.so` (soname
+    `libamdhip64.so.7`, found through torch's rpath), the library links `/opt/rocm`'s of the same
+    soname.  Whichever is loaded first serves every later request for that SONAME, but torch asks by
+    file name: if the system runtime came first, torch loads its own copy next to it, the second
+    runtime finds no GPU, and device pointers could not be exchanged with `torch.distributed`
+    anyway.  So when torch is installed, its runtime is loaded first (by path, without importing
+    torch) and both sides share it.  CLIVE2_SYSTEM_HIP=1 keeps the system runtime (no torch interop)."""
+    import sys
+    if os.environ.get("CLIVE2_SYSTEM_HIP") == "1" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass                                  # fall back to the runtime the library was linked against
+
+
 def lib():
     """Load the library (never builds implicitly on a box without the sources' toolchain)."""
     global _lib
@@ -81,6 +104,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RendererError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the render path.")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         L.cl2_last_error.restype = C.c_char_p
         L.cl2_last_error.argtypes = [C.c_void_p]

@@ -95,7 +95,7 @@ __device__ __forceinline__ Hit closest_hit_impl(const BvhLds& s, const BvhView& 
         if (tmin <= tmax && tmin < best.t) {
             const int info = __float_as_int(hi.w);
             if (info < 0) {
-                next = node + 1;                       // right child first (trace.metal:158-159): adjacent record
+                next = ~info;                          // right child first (trace.metal:158-159)
             } else {
                 const int left = info >> 4, right = left + (info & 15) + 1;
                 for (int i = left; i < right; i++) {   // trace.metal:161-172
@@ -237,7 +237,7 @@ __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhVi
                 float4 lo, hi;
                 if (node < b.n_lds_nodes) { lo = s.nodes[2 * node]; hi = s.nodes[2 * node + 1]; }
                 else { lo = b.nodes[2 * node]; hi = b.nodes[2 * node + 1]; }
-                const int cur = node, next = __float_as_int(lo.w);
+                const int next = __float_as_int(lo.w);
                 if (COUNT) n_box++;
                 const float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
                 const float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
@@ -253,7 +253,7 @@ __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhVi
                 node = next;
                 if (tmin <= tmax && tmin < best.t) {
                     const int info = __float_as_int(hi.w);
-                    if (info < 0) node = cur + 1;
+                    if (info < 0) node = ~info;
                     else { tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
                 }
             } else {

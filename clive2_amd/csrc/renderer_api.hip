@@ -452,6 +452,27 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
             rec_index[b.left] = rec_index[i] + 1 + subtree[b.left + 1];          // left child: after the right subtree
         }
     }
+    // ---- record numbering.  Small trees: plain visit order.  Trees larger than the LDS window: the
+    // boxes of the TOP levels (the reference array is breadth-first, so a prefix of it) are numbered
+    // first, [0, n_top), so that the window staged in LDS holds the records every ray visits; the rest
+    // keep their visit order behind them.  Links are explicit (skip, and the right child in `info`),
+    // so the numbering has no influence on the walk. ----
+    int n_top = 0;
+    if (n_records > LDS_NODE_CAP) {
+        while (n_top < n_boxes && n_top < LDS_NODE_CAP && (boxes[n_top].right == 0 || leaf_records(boxes[n_top]) == 1)) n_top++;
+    }
+    std::vector<int> renum((size_t)n_records + 1);
+    {
+        std::vector<char> is_top((size_t)n_records, 0);
+        for (int i = 0; i < n_top; i++) is_top[rec_index[i]] = 1;
+        int tops_before = 0;
+        for (int k = 0; k < n_records; k++) {
+            if (is_top[k]) { tops_before++; continue; }
+            renum[k] = n_top + k - tops_before;
+        }
+        for (int i = 0; i < n_top; i++) renum[rec_index[i]] = i;
+        renum[n_records] = n_records;
+    }
     for (int t = 0; t < n_tris; t++) {
         if (tris[t].material < 0 || tris[t].material >= n_mats) return fail(r, CL2_E_INVALID, "triangle material index out of range");
     }
@@ -467,22 +488,24 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     const float inf = std::numeric_limits<float>::infinity();
     for (int i = 0; i < n_boxes; i++) {
         const BoxRec& b = boxes[i];
-        const int k = rec_index[i], skip = k + subtree[i];
+        const int k = rec_index[i], skip = renum[k + subtree[i]];
         if (b.right == 0) {
-            h_nodes[2 * (size_t)k] = make_float4(b.min[0], b.min[1], b.min[2], as_f(skip));
-            h_nodes[2 * (size_t)k + 1] = make_float4(b.max[0], b.max[1], b.max[2], as_f(-1));
+            // inner: info = ~(record of the right child, visited first), negative
+            h_nodes[2 * (size_t)renum[k]] = make_float4(b.min[0], b.min[1], b.min[2], as_f(skip));
+            h_nodes[2 * (size_t)renum[k] + 1] = make_float4(b.max[0], b.max[1], b.max[2], as_f(~renum[k + 1]));
         } else {
             int begin = b.left;
             for (int part = 0; begin < b.right; part++, begin += LEAF_PACK_MAX) {
                 const int count = std::min(LEAF_PACK_MAX, b.right - begin);
                 const int info = (begin << 4) | (count - 1);
                 // follow-up records of an oversized leaf: an unbounded box, so they are always entered
-                const float4 lo = part == 0 ? make_float4(b.min[0], b.min[1], b.min[2], as_f(k + part + 1))
-                                            : make_float4(-inf, -inf, -inf, as_f(k + part + 1));
+                const int nxt = renum[k + part + 1];
+                const float4 lo = part == 0 ? make_float4(b.min[0], b.min[1], b.min[2], as_f(nxt))
+                                            : make_float4(-inf, -inf, -inf, as_f(nxt));
                 const float4 hi = part == 0 ? make_float4(b.max[0], b.max[1], b.max[2], as_f(info))
                                             : make_float4(inf, inf, inf, as_f(info));
-                h_nodes[2 * (size_t)(k + part)] = lo;
-                h_nodes[2 * (size_t)(k + part) + 1] = hi;
+                h_nodes[2 * (size_t)renum[k + part]] = lo;
+                h_nodes[2 * (size_t)renum[k + part] + 1] = hi;
             }
         }
     }

@@ -192,12 +192,13 @@ class Renderer:
         a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
         self._check(self._L.cl2_write_accumulators_packed(self._h, ptr(a), C.c_size_t(a.size)), "write_packed")
 
-    def reduce_accumulators(self, group=None):
+    def reduce_accumulators(self, group=None, always=False):
         """All-reduce (sum) the accumulators over the ranks of a torch.distributed group.  On GPUs
-        the message stays in HBM (RCCL); with a CPU backend (gloo) it goes through the host."""
+        the message stays in HBM (RCCL); with a CPU backend (gloo) it goes through the host.
+        A one-rank group is a no-op unless `always` (used to exercise the RCCL path on one GPU)."""
         import torch
         import torch.distributed as dist
-        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always):
             return
         n = 8 * self.batch_size
         if dist.get_backend(group) == "nccl":

@@ -68,3 +68,13 @@ def test_sample_partition():
     for total, world in ((1024, 8), (10, 4), (3, 8)):
         parts = [samples_for_rank(total, r, world) for r in range(world)]
         assert sum(parts) == total and max(parts) - min(parts) <= 1
+
+
+def test_movie_frames_are_split_without_overlap():
+    """Turntable frames are independent units (movie.py:29-55): every frame goes to exactly one rank."""
+    from clive2_amd.movie import frames_for_rank
+    for start, total, world in ((0, 120, 8), (7, 120, 8), (0, 5, 8), (3, 3, 2), (0, 1, 1)):
+        parts = [frames_for_rank(start, total, r, world) for r in range(world)]
+        flat = sorted(f for p in parts for f in p)
+        assert flat == list(range(start, total))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1

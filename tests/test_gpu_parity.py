@@ -357,3 +357,40 @@ def test_render_cli_writes_an_image(tmp_path):
     assert img.shape == (36, 64, 3) and img.std() > 1          # a picture, not a constant
     with pytest.raises(ValueError):
         render.main(["--scene", "no-such-preset", "--width", "8", "--height", "8", "--samples", "1"])
+
+
+def test_rccl_reduce_path_on_one_rank(cornell_small):
+    """The N>1 reduction as bench.py runs it -- accumulators handed to RCCL as a device buffer and
+    written back -- on a one-rank nccl group: the sum over one rank must return the same bytes."""
+    import os, socket
+    import torch
+    import torch.distributed as dist
+    from clive2_amd.renderer import Renderer, make_seeds
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B = cornell_small.pixel_width * cornell_small.pixel_height
+        r = Renderer(cornell_small, seeds=make_seeds(B))
+        r.run_samples(2)
+        before = r.packed_accumulators().copy()
+        r.reduce_accumulators(always=True)
+        assert r.packed_accumulators().tobytes() == before.tobytes()
+        r.run_samples(1)                                  # the renderer keeps working after the hand-over
+        assert np.isfinite(r.packed_accumulators()).all()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_movie_cli_writes_turntable_frames(tmp_path):
+    """The reference's turntable loop (movie.py:29-55): one scene + renderer per frame, one PNG each."""
+    from clive2_amd import movie
+    from PIL import Image
+    rc = movie.main(["--scene", "empty", "--width", "48", "--height", "32", "--samples", "2", "--movie-frames", "3",
+                     "--movie-name", "tt", "--out-root", str(tmp_path)])
+    assert rc == 0
+    frames = [np.asarray(Image.open(tmp_path / "tt" / f"frame_{f:04d}.png")) for f in range(3)]
+    assert all(fr.shape == (32, 48, 3) for fr in frames)
+    assert not np.array_equal(frames[0], frames[1])        # the camera moved
