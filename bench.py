@@ -101,6 +101,7 @@ def main():
                     help="cornell = the BASELINE metric's workload (default); the others are the mesh configs "
                          "(SURVEY 8d C3-C5 stand-ins), for profiling only")
     ap.add_argument("--levels-per-launch", type=int, default=6, help="subpath bounces per launch (1..6)")
+    ap.add_argument("--pipelining", type=int, default=1, help="sample pipeline: 0 serial, 1 subpaths of sample i+1 beside the connection phase of sample i (default), 2 three stages")
     ap.add_argument("--traversal-mode", type=int, default=0, help="0 auto, 1 fused, 2 persistent traversal with ray replacement")
     ap.add_argument("--cpu-width", type=int, default=1920)
     ap.add_argument("--cpu-height", type=int, default=1080)
@@ -149,6 +150,7 @@ def main():
 
     r.set_levels_per_launch(args.levels_per_launch)
     r.set_traversal_mode(args.traversal_mode)
+    r.set_pipelining(args.pipelining)
 
     # untimed: warm-up (also the counting pass that measures N_node / N_tri per ray)
     r.set_counting(True)
@@ -173,13 +175,17 @@ def main():
 
     c = r.counters()
     rays_local = c["rays"]
-    # untimed: per-stage breakdown (HIP events around every launch) over a few more samples
+    # untimed: per-stage breakdown (HIP events around every launch) over a few more samples, in serial
+    # order on one stream -- with the sample pipeline on, spans of the two streams overlap and a
+    # stage's span includes whatever ran beside it
     n_break = min(args.steps, 8)
     r.reset_counters()
     r.set_profiling(2)
+    r.set_pipelining(False)
     r.run_samples(n_break)
     cb = r.counters()
     r.set_profiling(0)
+    r.set_pipelining(args.pipelining)
     if world > 1:
         t = torch.tensor([float(rays_local), dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         tmax = t.clone()
@@ -219,8 +225,11 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_ray": round(b_ray, 1), "n_node": round(n_node, 3), "n_tri": round(n_tri, 3),
                          "rays_per_launch": round(k_rays / max(k_launches, 1)),
-                         "avg_launch_ms": round(k_ms / max(k_launches, 1), 4)},
-            "stage_ms_per_step": stages,
+                         "avg_launch_ms": round(k_ms / max(k_launches, 1), 4),
+                         # the same launch with nothing beside it (serial breakdown pass below)
+                         "avg_launch_ms_serial": round(cb["ms_traverse_conn"] / max(cb["launches_traverse_conn"], 1), 4),
+                         "sample_pipeline_stages": args.pipelining},
+            "stage_ms_per_step_serial": stages,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_width, args.cpu_height, args.cpu_samples)

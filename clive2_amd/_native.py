@@ -43,7 +43,7 @@ EXPORTS = [
     "cl2_create", "cl2_destroy", "cl2_last_error", "cl2_abi_version", "cl2_build_bvh", "cl2_upload_scene", "cl2_set_seeds",
     "cl2_get_seeds", "cl2_make_light_rays", "cl2_make_camera_rays", "cl2_trace_light_rays",
     "cl2_trace_camera_rays", "cl2_join_paths", "cl2_finalize_samples", "cl2_gather_light_image",
-    "cl2_process_images", "cl2_run_samples", "cl2_set_levels_per_launch", "cl2_set_traversal_mode", "cl2_read_accumulators", "cl2_reset_accumulators",
+    "cl2_process_images", "cl2_run_samples", "cl2_set_levels_per_launch", "cl2_set_traversal_mode", "cl2_set_pipelining", "cl2_read_accumulators", "cl2_reset_accumulators",
     "cl2_read_accumulators_packed", "cl2_write_accumulators_packed", "cl2_copy_accumulators_to_device",
     "cl2_copy_accumulators_from_device", "cl2_set_profiling", "cl2_set_counting", "cl2_set_debug_flags", "cl2_read_counters",
     "cl2_reset_counters", "cl2_selftest_exact_math", "cl2_export_rays", "cl2_export_paths", "cl2_export_aggregators",

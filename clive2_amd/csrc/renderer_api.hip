@@ -42,7 +42,11 @@ template <typename T> struct DevBuf {
 
 struct cl2_renderer {
     int device = 0, W = 0, H = 0, B = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // subpath phase (and everything else when not pipelining)
+    hipStream_t stream_conn = nullptr;   // sample pipeline: connection set-up + connection rays
+    hipStream_t stream_res = nullptr;    // sample pipeline: resolve + K6 + accumulation
+    hipEvent_t ev_paths[3] = {}, ev_conn[2] = {}, ev_res[6] = {};
+    int pipelining = 1;                  // sample pipeline inside cl2_run_samples: 0 serial, 1 two stages, 2 three stages
     std::string err;
     bool scene_ok = false, counting = false;
     int profiling = 0;                   // 0 off, 1 the connection-ray traversal launch only, 2 every stage
@@ -62,13 +66,14 @@ struct cl2_renderer {
 
     // state
     uint2* d_seeds = nullptr;
-    PathBufs pb[2]{};
+    PathBufs sets[3][2]{};             // subpath buffer sets of the sample pipeline
+    int cur = 0;                       // the set stage calls and exports use (after run_samples: the last sample's)
     float4* d_hit = nullptr;
     int* d_queue = nullptr;            // [6][B], shared by both subpath kinds (they run one after the other)
     unsigned* d_qcount = nullptr;      // [8]: [0] = B (level-0 count), [1..6] level counts, [7] connection rays
     int* d_ctag = nullptr;             // connection-ray queue: {slot, pixel} tags
-    float2* d_chit = nullptr;
-    unsigned long long* d_cmask = nullptr;
+    float2* d_chit[2] = {nullptr, nullptr};            // two sets: connection rays of sample i+1 vs resolve of sample i
+    unsigned long long* d_cmask[2] = {nullptr, nullptr};
     float* d_agg = nullptr;
     float4 *d_light_image = nullptr, *d_finalized = nullptr, *d_uni = nullptr;
     float* d_sample_w = nullptr;
@@ -127,18 +132,20 @@ hipEvent_t take_event(cl2_renderer* r) {
 }
 
 struct Timed {   // records a HIP-event span around a launch when profiling is on
-    cl2_renderer* r; int stage; hipEvent_t a = nullptr;
-    Timed(cl2_renderer* r_, int st) : r(r_), stage(st) {
-        const bool wanted = r->profiling >= 2 || (r->profiling == 1 && st == ST_TRAVERSE_CONN);
-        if (wanted) { a = take_event(r); (void)hipEventRecord(a, r->stream); }
+    cl2_renderer* r; int stage; hipStream_t st; hipEvent_t a = nullptr;
+    Timed(cl2_renderer* r_, int stage_, hipStream_t st_) : r(r_), stage(stage_), st(st_) {
+        const bool wanted = r->profiling >= 2 || (r->profiling == 1 && stage == ST_TRAVERSE_CONN);
+        if (wanted) { a = take_event(r); (void)hipEventRecord(a, st); }
     }
     ~Timed() {
-        if (a) { hipEvent_t b = take_event(r); (void)hipEventRecord(b, r->stream); r->spans.push_back({a, b, stage}); }
+        if (a) { hipEvent_t b = take_event(r); (void)hipEventRecord(b, st); r->spans.push_back({a, b, stage}); }
     }
 };
 
 int drain(cl2_renderer* r) {
     HIP_TRY(r, hipStreamSynchronize(r->stream));
+    HIP_TRY(r, hipStreamSynchronize(r->stream_conn));
+    HIP_TRY(r, hipStreamSynchronize(r->stream_res));
     for (auto& s : r->spans) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) r->ms[s.stage] += ms;
@@ -149,15 +156,15 @@ int drain(cl2_renderer* r) {
     return CL2_OK;
 }
 
-// ---- launches (asynchronous on r->stream) ----
-int launch_generate(cl2_renderer* r, int which) {
-    Timed t(r, ST_GENERATE);
+// ---- launches (asynchronous on the given stream; `set` = the two subpath buffers of the sample) ----
+int launch_generate(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set) {
+    Timed t(r, ST_GENERATE, st);
     if (which == CL2_LIGHT)
-        hipLaunchKernelGGL(k_gen_light_rays, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->d_light_tris,
-                           r->d_light_areas, r->d_light_tri_index, r->d_mats, r->light_count, r->d_seeds, r->pb[CL2_LIGHT]);
+        hipLaunchKernelGGL(k_gen_light_rays, dim3(grid_for(r->B)), dim3(BLOCK), 0, st, r->B, r->d_light_tris,
+                           r->d_light_areas, r->d_light_tri_index, r->d_mats, r->light_count, r->d_seeds, set[CL2_LIGHT]);
     else
-        hipLaunchKernelGGL(k_gen_camera_rays, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->cam, r->d_seeds,
-                           r->pb[CL2_CAMERA]);
+        hipLaunchKernelGGL(k_gen_camera_rays, dim3(grid_for(r->B)), dim3(BLOCK), 0, st, r->B, r->cam, r->d_seeds,
+                           set[CL2_CAMERA]);
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;
 }
@@ -170,12 +177,14 @@ inline bool split_mode(const cl2_renderer* r) {
 }
 inline int persistent_grid() { return 256 * 8; }      // 256 CUs x 8 workgroups of 4 waves = 32 waves per CU
 
-int launch_trace(cl2_renderer* r, int which) {
+// Subpath phase scratch (d_queue, d_qcount[0..6], d_work[0..6], d_hit, d_block_stats) is touched by this
+// phase only; the connection phase owns d_qcount[7] and d_work[7].
+int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set) {
     const int B = r->B;
-    PathBufs pb = r->pb[which];
-    HIP_TRY(r, hipMemsetAsync(r->d_qcount + 1, 0, 6 * sizeof(unsigned), r->stream));
+    PathBufs pb = set[which];
+    HIP_TRY(r, hipMemsetAsync(r->d_qcount + 1, 0, 6 * sizeof(unsigned), st));
     const bool split = split_mode(r);
-    if (split) HIP_TRY(r, hipMemsetAsync(r->d_work, 0, 8 * sizeof(unsigned), r->stream));
+    if (split) HIP_TRY(r, hipMemsetAsync(r->d_work, 0, 7 * sizeof(unsigned), st));
     const int step = split ? 1 : std::max(1, std::min(r->levels_per_launch, (int)MAX_VERTS));
     for (int first = 0; first < MAX_VERTS; first += step) {
         const int end = std::min(first + step, (int)MAX_VERTS);
@@ -185,20 +194,20 @@ int launch_trace(cl2_renderer* r, int which) {
         int* q_out = r->d_queue + (size_t)(end - 1) * B;
         unsigned* c_out = r->d_qcount + end;
         if (split) {
-            Timed t(r, ST_TRAVERSE_PATHS);
+            Timed t(r, ST_TRAVERSE_PATHS, st);
             PathRaySource src{q_in, pb.P0 + (size_t)first * B, pb.P1 + (size_t)first * B, r->d_hit};
             if (r->counting)
-                hipLaunchKernelGGL((k_traverse_persistent<true, PathRaySource>), dim3(persistent_grid()), dim3(BLOCK), 0, r->stream,
+                hipLaunchKernelGGL((k_traverse_persistent<true, PathRaySource>), dim3(persistent_grid()), dim3(BLOCK), 0, st,
                                    r->bvh, c_in, r->d_work + first, src, r->d_stats, 0);
             else
-                hipLaunchKernelGGL((k_traverse_persistent<false, PathRaySource>), dim3(persistent_grid()), dim3(BLOCK), 0, r->stream,
+                hipLaunchKernelGGL((k_traverse_persistent<false, PathRaySource>), dim3(persistent_grid()), dim3(BLOCK), 0, st,
                                    r->bvh, c_in, r->d_work + first, src, r->d_stats, 0);
             r->launches_tp++;
             HIP_TRY(r, hipGetLastError());
         }
-        Timed t(r, split ? ST_BOUNCE : ST_TRAVERSE_PATHS);
+        Timed t(r, split ? ST_BOUNCE : ST_TRAVERSE_PATHS, st);
 #define CL2_TRACE(CAM, CNT, EXT)                                                                                          \
-        hipLaunchKernelGGL((k_trace_subpath<CAM, CNT, EXT>), dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, r->bvh, r->d_stats,  \
+        hipLaunchKernelGGL((k_trace_subpath<CAM, CNT, EXT>), dim3(grid_for(B)), dim3(BLOCK), 0, st, r->bvh, r->d_stats,          \
                            first, end, q_in, c_in, q_out, c_out, B, pb, r->d_seeds, r->d_tri_shade, r->d_mats, r->n_mats,        \
                            r->d_block_stats, r->d_hit)
         if (split) { if (which == CL2_CAMERA) CL2_TRACE(true, false, true); else CL2_TRACE(false, false, true); }
@@ -211,46 +220,55 @@ int launch_trace(cl2_renderer* r, int which) {
     return CL2_OK;
 }
 
-int launch_join(cl2_renderer* r) {
+// connection set-up + connection rays; `cs` = which {chit, cmask} set
+int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs) {
     const int B = r->B;
-    HIP_TRY(r, hipMemsetAsync(r->d_qcount + 7, 0, sizeof(unsigned), r->stream));
+    const PathBufs& lp = set[CL2_LIGHT];
+    const PathBufs& cp = set[CL2_CAMERA];
+    HIP_TRY(r, hipMemsetAsync(r->d_qcount + 7, 0, sizeof(unsigned), st));
     {
-        Timed t(r, ST_CONNECT_SETUP);
-        hipLaunchKernelGGL(k_connect_setup, dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, B, r->pb[CL2_LIGHT], r->pb[CL2_CAMERA],
-                           r->d_mats, r->cam, r->d_ctag, r->d_qcount + 7, r->d_cmask);
+        Timed t(r, ST_CONNECT_SETUP, st);
+        hipLaunchKernelGGL(k_connect_setup, dim3(grid_for(B)), dim3(BLOCK), 0, st, B, lp, cp,
+                           r->d_mats, r->cam, r->d_ctag, r->d_qcount + 7, r->d_cmask[cs]);
     }
     HIP_TRY(r, hipGetLastError());
     {
-        Timed t(r, ST_TRAVERSE_CONN);
+        Timed t(r, ST_TRAVERSE_CONN, st);
         if (split_mode(r)) {
-            HIP_TRY(r, hipMemsetAsync(r->d_work + 7, 0, sizeof(unsigned), r->stream));
-            ConnRaySource src{r->d_ctag, r->pb[CL2_LIGHT].P0, r->pb[CL2_CAMERA].P0, r->d_chit,
+            HIP_TRY(r, hipMemsetAsync(r->d_work + 7, 0, sizeof(unsigned), st));
+            ConnRaySource src{r->d_ctag, lp.P0, cp.P0, r->d_chit[cs],
                               V3{r->cam.focal_point[0], r->cam.focal_point[1], r->cam.focal_point[2]}, B};
             if (r->counting)
-                hipLaunchKernelGGL((k_traverse_persistent<true, ConnRaySource>), dim3(persistent_grid()), dim3(BLOCK), 0, r->stream,
+                hipLaunchKernelGGL((k_traverse_persistent<true, ConnRaySource>), dim3(persistent_grid()), dim3(BLOCK), 0, st,
                                    r->bvh, r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1);
             else
-                hipLaunchKernelGGL((k_traverse_persistent<false, ConnRaySource>), dim3(persistent_grid()), dim3(BLOCK), 0, r->stream,
+                hipLaunchKernelGGL((k_traverse_persistent<false, ConnRaySource>), dim3(persistent_grid()), dim3(BLOCK), 0, st,
                                    r->bvh, r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1);
         } else {
-        // grid-stride over the (device-side) ray count; enough workgroups to fill 256 CUs several times over
-        const int grid = std::min<size_t>(grid_for((size_t)B * 8), 256 * 32);
-        if (r->counting)
-            hipLaunchKernelGGL(k_traverse_conn<true>, dim3(grid), dim3(BLOCK), 0, r->stream, r->bvh, B, r->d_qcount + 7, r->d_ctag,
-                               r->pb[CL2_LIGHT].P0, r->pb[CL2_CAMERA].P0, r->cam, r->d_chit, r->d_stats);
-        else
-            hipLaunchKernelGGL(k_traverse_conn<false>, dim3(grid), dim3(BLOCK), 0, r->stream, r->bvh, B, r->d_qcount + 7, r->d_ctag,
-                               r->pb[CL2_LIGHT].P0, r->pb[CL2_CAMERA].P0, r->cam, r->d_chit, r->d_stats);
+            // grid-stride over the (device-side) ray count; enough workgroups to fill 256 CUs several times over
+            const int grid = std::min<size_t>(grid_for((size_t)B * 8), 256 * 32);
+            if (r->counting)
+                hipLaunchKernelGGL(k_traverse_conn<true>, dim3(grid), dim3(BLOCK), 0, st, r->bvh, B, r->d_qcount + 7, r->d_ctag,
+                                   lp.P0, cp.P0, r->cam, r->d_chit[cs], r->d_stats);
+            else
+                hipLaunchKernelGGL(k_traverse_conn<false>, dim3(grid), dim3(BLOCK), 0, st, r->bvh, B, r->d_qcount + 7, r->d_ctag,
+                                   lp.P0, cp.P0, r->cam, r->d_chit[cs], r->d_stats);
         }
         r->launches_tc++;
     }
     HIP_TRY(r, hipGetLastError());
+    return CL2_OK;
+}
+
+int launch_resolve(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs) {
+    const int B = r->B;
+    const PathBufs& lp = set[CL2_LIGHT];
+    const PathBufs& cp = set[CL2_CAMERA];
     {
-        Timed t(r, ST_CONNECT_RESOLVE);
+        Timed t(r, ST_CONNECT_RESOLVE, st);
 #define CL2_RESOLVE(W)                                                                                                       \
-        hipLaunchKernelGGL(k_connect_resolve<W>, dim3(grid_for(B)), dim3(BLOCK), 0, r->stream, B, r->pb[CL2_LIGHT],             \
-                           r->pb[CL2_CAMERA], r->d_mats, r->d_tri_shade, r->cam, r->d_cmask, r->d_chit, r->d_agg,               \
-                           r->d_light_image, r->d_uni, r->d_stats, r->debug_flags)
+        hipLaunchKernelGGL(k_connect_resolve<W>, dim3(grid_for(B)), dim3(BLOCK), 0, st, B, lp, cp, r->d_mats, r->d_tri_shade,   \
+                           r->cam, r->d_cmask[cs], r->d_chit[cs], r->d_agg, r->d_light_image, r->d_uni, r->d_stats, r->debug_flags)
         const int occ = (r->debug_flags >> 4) & 7;      // experiment switch: register budget of the resolve kernel
         if (occ == 2) CL2_RESOLVE(2); else if (occ == 4) CL2_RESOLVE(4); else CL2_RESOLVE(3);
 #undef CL2_RESOLVE
@@ -259,17 +277,17 @@ int launch_join(cl2_renderer* r) {
     return CL2_OK;
 }
 
-int launch_finalize(cl2_renderer* r) {
-    Timed t(r, ST_FINALIZE);
-    hipLaunchKernelGGL(k_finalize, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->W, r->H, r->d_agg, r->d_finalized,
+int launch_finalize(cl2_renderer* r, hipStream_t st) {
+    Timed t(r, ST_FINALIZE, st);
+    hipLaunchKernelGGL(k_finalize, dim3(grid_for(r->B)), dim3(BLOCK), 0, st, r->B, r->W, r->H, r->d_agg, r->d_finalized,
                        r->d_sample_w);
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;
 }
 
-int launch_accumulate(cl2_renderer* r) {
-    Timed t(r, ST_ACCUMULATE);
-    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->d_finalized, r->d_sample_w,
+int launch_accumulate(cl2_renderer* r, hipStream_t st) {
+    Timed t(r, ST_ACCUMULATE, st);
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(r->B)), dim3(BLOCK), 0, st, r->B, r->d_finalized, r->d_sample_w,
                        r->d_light_image, r->d_uni, r->d_acc);
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;
@@ -343,21 +361,33 @@ int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_render
     const size_t B = (size_t)r->B;
     auto bail = [&](int code) { g_create_error = r->err; cl2_destroy(r); return code; };
     if (hipSetDevice(device_ordinal) != hipSuccess) { r->err = "hipSetDevice failed"; return bail(CL2_E_HIP); }
-    if (hipStreamCreate(&r->stream) != hipSuccess) { r->err = "hipStreamCreate failed"; return bail(CL2_E_HIP); }
+    if (hipStreamCreate(&r->stream) != hipSuccess || hipStreamCreate(&r->stream_conn) != hipSuccess ||
+        hipStreamCreate(&r->stream_res) != hipSuccess) {
+        r->err = "hipStreamCreate failed"; return bail(CL2_E_HIP);
+    }
+    {
+        bool ok_ev = true;
+        for (auto& e : r->ev_paths) ok_ev = ok_ev && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        for (auto& e : r->ev_conn) ok_ev = ok_ev && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        for (auto& e : r->ev_res) ok_ev = ok_ev && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (!ok_ev) { r->err = "hipEventCreate failed"; return bail(CL2_E_HIP); }
+    }
     int rc = CL2_OK;
 #define A(ptr, count) if (rc == CL2_OK) rc = dev_alloc(r, &(ptr), (count))
     A(r->d_seeds, B);
-    for (int k = 0; k < 2; k++) {
-        A(r->pb[k].P0, MAX_VERTS * B); A(r->pb[k].P1, MAX_VERTS * B); A(r->pb[k].P2, MAX_VERTS * B); A(r->pb[k].P3, MAX_VERTS * B);
-        A(r->pb[k].tri, MAX_VERTS * B); A(r->pb[k].len, B); A(r->pb[k].carry, B);
+    for (int q = 0; q < 3; q++) {
+        for (int k = 0; k < 2; k++) {
+            PathBufs& pb = r->sets[q][k];
+            A(pb.P0, MAX_VERTS * B); A(pb.P1, MAX_VERTS * B); A(pb.P2, MAX_VERTS * B); A(pb.P3, MAX_VERTS * B);
+            A(pb.tri, MAX_VERTS * B); A(pb.len, B); A(pb.carry, B);
+        }
     }
     A(r->d_hit, B);
     A(r->d_queue, MAX_VERTS * B);
     A(r->d_qcount, 8);
     A(r->d_work, 8);
     A(r->d_ctag, (size_t)CONN_SLOTS * B);
-    A(r->d_chit, (size_t)CONN_SLOTS * B);
-    A(r->d_cmask, B);
+    for (int q = 0; q < 2; q++) { A(r->d_chit[q], (size_t)CONN_SLOTS * B); A(r->d_cmask[q], B); }
     A(r->d_agg, (size_t)AGG_ROWS * B);
     A(r->d_light_image, B); A(r->d_finalized, B); A(r->d_uni, B);
     A(r->d_sample_w, B);
@@ -376,8 +406,9 @@ int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_render
     ok = ok && hipMemset(r->d_agg, 0, (size_t)AGG_ROWS * B * sizeof(float)) == hipSuccess;
     ok = ok && hipMemset(r->d_stats, 0, sizeof(Stats)) == hipSuccess;
     ok = ok && hipMemset(r->d_block_stats, 0, (size_t)grid_for(B) * 4 * sizeof(unsigned long long)) == hipSuccess;
-    ok = ok && hipMemset(r->d_cmask, 0, B * sizeof(unsigned long long)) == hipSuccess;
-    for (int k = 0; k < 2 && ok; k++) ok = hipMemset(r->pb[k].len, 0, B * sizeof(int)) == hipSuccess;
+    for (int q = 0; q < 2 && ok; q++) ok = hipMemset(r->d_cmask[q], 0, B * sizeof(unsigned long long)) == hipSuccess;
+    for (int q = 0; q < 3 && ok; q++)
+        for (int k = 0; k < 2 && ok; k++) ok = hipMemset(r->sets[q][k].len, 0, B * sizeof(int)) == hipSuccess;
     // default seeds: 1 everywhere (xorshift's only forbidden state is 0); callers set real seeds
     if (ok) {
         std::vector<uint32_t> ones(2 * B, 1u);
@@ -392,10 +423,17 @@ void cl2_destroy(cl2_renderer* r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
     if (r->stream) (void)hipStreamSynchronize(r->stream);
+    if (r->stream_conn) (void)hipStreamSynchronize(r->stream_conn);
+    if (r->stream_res) (void)hipStreamSynchronize(r->stream_res);
+    for (auto e : r->ev_paths) if (e) (void)hipEventDestroy(e);
+    for (auto e : r->ev_conn) if (e) (void)hipEventDestroy(e);
+    for (auto e : r->ev_res) if (e) (void)hipEventDestroy(e);
     for (auto& s : r->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : r->event_pool) (void)hipEventDestroy(e);
     for (void* p : r->allocs) (void)hipFree(p);
     if (r->stream) (void)hipStreamDestroy(r->stream);
+    if (r->stream_conn) (void)hipStreamDestroy(r->stream_conn);
+    if (r->stream_res) (void)hipStreamDestroy(r->stream_res);
     delete r;
 }
 
@@ -583,38 +621,82 @@ int cl2_get_seeds(cl2_renderer* r, uint32_t* seeds, size_t n_words) {
     return CL2_OK;
 }
 
-int cl2_make_light_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_generate(r, CL2_LIGHT)); return drain(r); }
-int cl2_make_camera_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_generate(r, CL2_CAMERA)); return drain(r); }
-int cl2_trace_light_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_trace(r, CL2_LIGHT)); return drain(r); }
-int cl2_trace_camera_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_trace(r, CL2_CAMERA)); return drain(r); }
-int cl2_join_paths(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_join(r)); return drain(r); }
-int cl2_finalize_samples(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_finalize(r)); return drain(r); }
+int cl2_make_light_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_generate(r, CL2_LIGHT, r->stream, r->sets[r->cur])); return drain(r); }
+int cl2_make_camera_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_generate(r, CL2_CAMERA, r->stream, r->sets[r->cur])); return drain(r); }
+int cl2_trace_light_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_trace(r, CL2_LIGHT, r->stream, r->sets[r->cur])); return drain(r); }
+int cl2_trace_camera_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_trace(r, CL2_CAMERA, r->stream, r->sets[r->cur])); return drain(r); }
+int cl2_join_paths(cl2_renderer* r) {
+    STAGE_PROLOGUE(r);
+    TRY(launch_connect(r, r->stream, r->sets[r->cur], 0));
+    TRY(launch_resolve(r, r->stream, r->sets[r->cur], 0));
+    return drain(r);
+}
+int cl2_finalize_samples(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_finalize(r, r->stream)); return drain(r); }
 /* The t=1 splats were added to the light image by join_paths (float atomics); nothing is left of the
  * reference's sort + bincount + gather (src/renderer.py:212-250) but a synchronisation point. */
 int cl2_gather_light_image(cl2_renderer* r) { STAGE_PROLOGUE(r); return drain(r); }
 int cl2_process_images(cl2_renderer* r) {
     STAGE_PROLOGUE(r);
-    TRY(launch_accumulate(r));
+    TRY(launch_accumulate(r, r->stream));
     r->samples++;
     return drain(r);
 }
 
+/* n x run_sample as a three-stage pipeline over samples.  The only state a sample hands to the next
+ * one is the seed buffer, and only the subpath stage (K1, K2, K3) touches it.  So with three subpath
+ * buffer sets and two {hit, mask} sets
+ *     stream       : subpaths of sample i+2
+ *     stream_conn  : connection set-up + connection rays of sample i+1
+ *     stream_res   : resolve, K6, accumulation of sample i
+ * run side by side.  Every launch ends in a tail of a few long rays or late workgroups, the
+ * streaming kernels leave the VALUs idle and the resolve kernel the memory system: the other stages'
+ * workgroups fill what is left.  Each kernel sees exactly the inputs it would see in the serial
+ * order (sums into the accumulators stay in sample order on stream_res), so results do not change. */
 int cl2_run_samples(cl2_renderer* r, int n) {
     STAGE_PROLOGUE(r);
     if (n < 0) return fail(r, CL2_E_INVALID, "negative sample count");
+    const bool pipe = r->pipelining != 0 && n > 1;
+    const int first_set = r->cur;
     for (int i = 0; i < n; i++) {
-        TRY(launch_generate(r, CL2_LIGHT));
-        TRY(launch_generate(r, CL2_CAMERA));
-        TRY(launch_trace(r, CL2_LIGHT));
-        TRY(launch_trace(r, CL2_CAMERA));
-        TRY(launch_join(r));
-        TRY(launch_finalize(r));
-        TRY(launch_accumulate(r));
+        const int ps = pipe ? (first_set + i) % 3 : r->cur, cs = pipe ? (i & 1) : 0;
+        const PathBufs* set = r->sets[ps];
+        hipStream_t s_conn = pipe ? r->stream_conn : r->stream;
+        hipStream_t s_res = pipe ? (r->pipelining == 2 ? r->stream_res : r->stream_conn) : r->stream;
+        // resolve of sample i-3 was the last reader of this subpath set
+        if (pipe && i >= 3) HIP_TRY(r, hipStreamWaitEvent(r->stream, r->ev_res[(i - 3) % 6], 0));
+        TRY(launch_generate(r, CL2_LIGHT, r->stream, set));
+        TRY(launch_generate(r, CL2_CAMERA, r->stream, set));
+        TRY(launch_trace(r, CL2_LIGHT, r->stream, set));
+        TRY(launch_trace(r, CL2_CAMERA, r->stream, set));
+        if (pipe) {
+            HIP_TRY(r, hipEventRecord(r->ev_paths[i % 3], r->stream));
+            HIP_TRY(r, hipStreamWaitEvent(s_conn, r->ev_paths[i % 3], 0));
+            // resolve of sample i-2 was the last reader of this {hit, mask} set
+            if (i >= 2) HIP_TRY(r, hipStreamWaitEvent(s_conn, r->ev_res[(i - 2) % 6], 0));
+        }
+        TRY(launch_connect(r, s_conn, set, cs));
+        if (pipe) {
+            HIP_TRY(r, hipEventRecord(r->ev_conn[i & 1], s_conn));
+            HIP_TRY(r, hipStreamWaitEvent(s_res, r->ev_conn[i & 1], 0));
+        }
+        TRY(launch_resolve(r, s_res, set, cs));
+        TRY(launch_finalize(r, s_res));
+        TRY(launch_accumulate(r, s_res));
+        if (pipe) HIP_TRY(r, hipEventRecord(r->ev_res[i % 6], s_res));
         r->samples++;
         // bound the number of in-flight event pairs while profiling
         if (r->profiling && r->spans.size() > 4096) TRY(drain(r));
     }
-    return drain(r);
+    TRY(drain(r));
+    if (pipe && n > 0) r->cur = (first_set + n - 1) % 3;         // exports show the last sample's subpaths
+    return CL2_OK;
+}
+
+int cl2_set_pipelining(cl2_renderer* r, int on) {
+    if (!r) return CL2_E_INVALID;
+    if (on < 0 || on > 2) return fail(r, CL2_E_INVALID, "pipelining must be 0..2");
+    r->pipelining = on;
+    return CL2_OK;
 }
 
 int cl2_read_accumulators(cl2_renderer* r, float* img, float* wts, int32_t* counts, float* uni, size_t n_pixels) {
@@ -769,7 +851,7 @@ int cl2_export_rays(cl2_renderer* r, int which, void* out, size_t n_records) {
     if (!out || (which != CL2_LIGHT && which != CL2_CAMERA) || n_records != (size_t)r->B) return fail(r, CL2_E_INVALID, "bad export_rays arguments");
     RayRec* d = nullptr;
     TRY(dev_alloc(r, &d, (size_t)r->B));
-    hipLaunchKernelGGL(k_export_rays, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->pb[which], which == CL2_CAMERA ? 1 : 0, d);
+    hipLaunchKernelGGL(k_export_rays, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->sets[r->cur][which], which == CL2_CAMERA ? 1 : 0, d);
     int rc = drain(r);
     if (rc == CL2_OK && hipMemcpy(out, d, (size_t)r->B * sizeof(RayRec), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(r, CL2_E_HIP, "export copy failed");
     dev_free(r, d);
@@ -781,7 +863,7 @@ int cl2_export_paths(cl2_renderer* r, int which, void* out, size_t n_records) {
     if (!out || (which != CL2_LIGHT && which != CL2_CAMERA) || n_records != (size_t)r->B) return fail(r, CL2_E_INVALID, "bad export_paths arguments");
     unsigned char* d = nullptr;
     TRY(dev_alloc(r, &d, (size_t)r->B * 1040));
-    hipLaunchKernelGGL(k_export_paths, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->pb[which], which == CL2_CAMERA ? 1 : 0, d);
+    hipLaunchKernelGGL(k_export_paths, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->sets[r->cur][which], which == CL2_CAMERA ? 1 : 0, d);
     int rc = drain(r);
     if (rc == CL2_OK && hipMemcpy(out, d, (size_t)r->B * 1040, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(r, CL2_E_HIP, "export copy failed");
     dev_free(r, d);

@@ -111,6 +111,16 @@ int cl2_set_levels_per_launch(cl2_renderer* r, int levels);
  * bounce launch per level (best for large trees: rays of very different cost), 0 = choose by scene
  * size (default).  Results are identical for every setting. */
 int cl2_set_traversal_mode(cl2_renderer* r, int mode);
+/* Sample pipeline of cl2_run_samples.  The seed buffer is the only state one sample hands to the next
+ * (src/renderer.py:86-87) and only the subpath stage (K1, K2, K3) touches it, so later stages of
+ * sample i can run beside the subpath stage of the following samples, on their own HIP streams and
+ * buffer sets; every kernel sees the inputs of the serial order, results are the same.  The
+ * reference's run_sample is strictly serial (src/renderer.py:281-291).
+ *   0  serial, one stream
+ *   1  two stages (default): subpaths of sample i+1 | connections, K6, accumulation of sample i
+ *   2  three stages: subpaths of i+2 | connection set-up + connection rays of i+1 | resolve, K6,
+ *      accumulation of i  (measured no faster than 1) */
+int cl2_set_pipelining(cl2_renderer* r, int stages);
 
 /* -- accumulators: Renderer.summed_image / summed_sample_weights / summed_sample_counts /
  *    unidirectional_image_buffer (src/renderer.py:41-45).  Any pointer may be NULL. -- */

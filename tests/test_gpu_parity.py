@@ -359,29 +359,26 @@ def test_render_cli_writes_an_image(tmp_path):
         render.main(["--scene", "no-such-preset", "--width", "8", "--height", "8", "--samples", "1"])
 
 
-def test_rccl_reduce_path_on_one_rank(cornell_small):
+def test_rccl_reduce_path_on_one_rank():
     """The N>1 reduction as bench.py runs it -- accumulators handed to RCCL as a device buffer and
-    written back -- on a one-rank nccl group: the sum over one rank must return the same bytes."""
-    import os, socket
-    import torch
-    import torch.distributed as dist
-    from clive2_amd.renderer import Renderer, make_seeds
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    written back -- on a one-rank nccl group: the sum over one rank must return the same bytes.
+    Runs in a child process (tests/rccl_one_rank_child.py) under a time limit: a communicator that
+    hangs while it is created or torn down (seen once on this pool) must not take the suite with it."""
+    import os, subprocess, sys
+    child = os.path.join(os.path.dirname(__file__), "rccl_one_rank_child.py")
     try:
-        B = cornell_small.pixel_width * cornell_small.pixel_height
-        r = Renderer(cornell_small, seeds=make_seeds(B))
-        r.run_samples(2)
-        before = r.packed_accumulators().copy()
-        r.reduce_accumulators(always=True)
-        assert r.packed_accumulators().tobytes() == before.tobytes()
-        r.run_samples(1)                                  # the renderer keeps working after the hand-over
-        assert np.isfinite(r.packed_accumulators()).all()
-    finally:
-        dist.destroy_process_group()
+        p = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=240)
+        out, rc = p.stdout, p.returncode
+    except subprocess.TimeoutExpired as e:
+        out, rc = (e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or ""), None
+    steps = [l.split()[1] for l in out.splitlines() if l.startswith("STEP ")]
+    if rc is None:
+        if "handover-ok" in steps:
+            return                                   # the hand-over was verified; the hang is in the teardown
+        if "group-up" not in steps:
+            pytest.skip(f"RCCL communicator creation hung on this box (steps reached: {steps})")
+        pytest.fail(f"hung after {steps}")
+    assert rc == 0 and "handover-ok" in steps and "render-after-ok" in steps, (rc, out[-2000:], p.stderr[-2000:])
 
 
 def test_movie_cli_writes_turntable_frames(tmp_path):
@@ -394,3 +391,33 @@ def test_movie_cli_writes_turntable_frames(tmp_path):
     frames = [np.asarray(Image.open(tmp_path / "tt" / f"frame_{f:04d}.png")) for f in range(3)]
     assert all(fr.shape == (32, 48, 3) for fr in frames)
     assert not np.array_equal(frames[0], frames[1])        # the camera moved
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_sample_pipeline_is_a_pure_performance_knob(mode, glass_scene, oracle_mod):
+    """run_samples as a pipeline over samples (later stages of sample i on their own streams beside
+    the subpath stage of the next samples; 2 and 3 stages) == serial order == oracle: seeds, last
+    subpaths, accumulators."""
+    n = 5
+    r1, o = _pair(glass_scene, oracle_mod)
+    r2, _ = _pair(glass_scene, oracle_mod)
+    r3, _ = _pair(glass_scene, oracle_mod)
+    for r, stages in ((r1, 1), (r2, 0), (r3, 2)):
+        r.set_traversal_mode(mode)
+        r.set_pipelining(stages)
+        r.run_samples(n)
+    for _ in range(n):
+        o.run_sample()
+    for r in (r1, r2, r3):
+        assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
+        for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
+            assert r.export_paths(which).tobytes() == ref.tobytes()       # the last sample's subpaths
+        img, wts, cnt, uni = r.read_accumulators()
+        assert (cnt == n).all()
+        np.testing.assert_allclose(uni, o.unidirectional_image_buffer, rtol=1e-6, atol=0)
+        np.testing.assert_allclose(img, o.summed_image, rtol=5e-5, atol=1e-8)
+        np.testing.assert_allclose(wts, o.summed_sample_weights, rtol=5e-5, atol=1e-8)
+        assert r.counters()["rays"] == o.rays_traced
+    assert r1.read_accumulators()[3].tobytes() == r2.read_accumulators()[3].tobytes() == r3.read_accumulators()[3].tobytes()
+    with pytest.raises(Exception):
+        r1.set_pipelining(3)
