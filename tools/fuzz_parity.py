@@ -54,9 +54,10 @@ def main():
         B = scene.pixel_width * scene.pixel_height
         seeds = make_seeds(B, seed=k)
         r, o = Renderer(scene, seeds=seeds), orc.OracleRenderer(scene, seeds=seeds)
-        mode, levels = int(rng.randint(0, 3)), int(rng.randint(1, 7))
+        mode, levels, stages = int(rng.randint(0, 3)), int(rng.randint(1, 7)), int(rng.randint(0, 3))
         r.set_traversal_mode(mode)
         r.set_levels_per_launch(levels)
+        r.set_pipelining(stages)
         t0 = time.time()
         ok = True
         for x in (r, o):
@@ -68,12 +69,15 @@ def main():
         agg = r.export_aggregators()
         ok &= agg["total_contribution"].tobytes() == o.weight_aggregators["total_contribution"].tobytes()
         ok &= agg["weights"].tobytes() == o.weight_aggregators["weights"].tobytes()
-        r.run_samples(2); o.run_sample(); o.run_sample()
+        r.run_samples(3); o.run_sample(); o.run_sample(); o.run_sample()
         ok &= bool(np.array_equal(r.get_random_buffer(), o.rand_buffer))
+        ok &= r.export_paths(0).tobytes() == o.out_light_paths.tobytes()      # the last sample's subpaths
+        ok &= r.export_paths(1).tobytes() == o.out_camera_paths.tobytes()
+        ok &= bool(np.allclose(r.read_accumulators()[3], o.unidirectional_image_buffer, rtol=1e-6, atol=0))
         img = r.read_accumulators()[0]
         ok &= bool(np.allclose(img, o.summed_image, rtol=5e-5, atol=1e-8))
         ok &= r.counters()["rays"] == o.rays_traced
-        print(f"scene {k}: {desc} tris={len(scene.triangles)} mode={mode} levels={levels} "
+        print(f"scene {k}: {desc} tris={len(scene.triangles)} mode={mode} levels={levels} stages={stages} "
               f"len_c={o.out_camera_paths['length'].mean():.2f} {'OK' if ok else 'MISMATCH'} ({time.time() - t0:.1f}s)", flush=True)
         bad += not ok
         r.close()
