@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -46,6 +47,8 @@ struct cl2_renderer {
     hipStream_t stream_conn = nullptr;   // sample pipeline: connection set-up + connection rays
     hipStream_t stream_res = nullptr;    // sample pipeline: resolve + K6 + accumulation
     hipEvent_t ev_paths[3] = {}, ev_conn[2] = {}, ev_res[6] = {};
+    bool pipe_active = false;            // inside a pipelined cl2_run_samples
+    int paths_share = 0;                 // eighths of the wave slots given to the subpath stage while pipelining (0 = not tuned yet)
     int pipelining = 1;                  // sample pipeline inside cl2_run_samples: 0 serial, 1 two stages, 2 three stages
     std::string err;
     bool scene_ok = false, counting = false;
@@ -176,6 +179,21 @@ inline bool split_mode(const cl2_renderer* r) {
     return r->traversal_mode == 2 || (r->traversal_mode == 0 && !all_lds);
 }
 inline int persistent_grid() { return 256 * 8; }      // 256 CUs x 8 workgroups of 4 waves = 32 waves per CU
+// While the sample pipeline runs, the subpath stage and the connection stage of two samples are on the
+// machine together.  Persistent launches hold their wave slots until the launch runs dry, so the two
+// stages get a fixed share of the slots each (in eighths of the machine): the stage whose launch is in
+// its tail (a few long rays) leaves the VALUs to the other one instead of leaving them idle.
+constexpr int TUNE_SAMPLES = 6;       // samples timed per candidate share
+inline int paths_eighths(const cl2_renderer* r) {
+    const int forced = (r->debug_flags >> 8) & 7;          // experiment switch
+    return forced ? forced : (r->paths_share ? r->paths_share : 4);
+}
+inline int persistent_grid_paths(const cl2_renderer* r) {
+    return r->pipe_active ? 256 * paths_eighths(r) : persistent_grid();
+}
+inline int persistent_grid_conn(const cl2_renderer* r) {
+    return r->pipe_active ? 256 * (8 - paths_eighths(r)) : persistent_grid();
+}
 
 // Subpath phase scratch (d_queue, d_qcount[0..6], d_work[0..6], d_hit, d_block_stats) is touched by this
 // phase only; the connection phase owns d_qcount[7] and d_work[7].
@@ -197,10 +215,10 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
             Timed t(r, ST_TRAVERSE_PATHS, st);
             PathRaySource src{q_in, pb.P0 + (size_t)first * B, pb.P1 + (size_t)first * B, r->d_hit};
             if (r->counting)
-                hipLaunchKernelGGL((k_traverse_persistent<true, PathRaySource>), dim3(persistent_grid()), dim3(BLOCK), 0, st,
+                hipLaunchKernelGGL((k_traverse_persistent<true, PathRaySource>), dim3(persistent_grid_paths(r)), dim3(BLOCK), 0, st,
                                    r->bvh, c_in, r->d_work + first, src, r->d_stats, 0);
             else
-                hipLaunchKernelGGL((k_traverse_persistent<false, PathRaySource>), dim3(persistent_grid()), dim3(BLOCK), 0, st,
+                hipLaunchKernelGGL((k_traverse_persistent<false, PathRaySource>), dim3(persistent_grid_paths(r)), dim3(BLOCK), 0, st,
                                    r->bvh, c_in, r->d_work + first, src, r->d_stats, 0);
             r->launches_tp++;
             HIP_TRY(r, hipGetLastError());
@@ -239,10 +257,10 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
             ConnRaySource src{r->d_ctag, lp.P0, cp.P0, r->d_chit[cs],
                               V3{r->cam.focal_point[0], r->cam.focal_point[1], r->cam.focal_point[2]}, B};
             if (r->counting)
-                hipLaunchKernelGGL((k_traverse_persistent<true, ConnRaySource>), dim3(persistent_grid()), dim3(BLOCK), 0, st,
+                hipLaunchKernelGGL((k_traverse_persistent<true, ConnRaySource>), dim3(persistent_grid_conn(r)), dim3(BLOCK), 0, st,
                                    r->bvh, r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1);
             else
-                hipLaunchKernelGGL((k_traverse_persistent<false, ConnRaySource>), dim3(persistent_grid()), dim3(BLOCK), 0, st,
+                hipLaunchKernelGGL((k_traverse_persistent<false, ConnRaySource>), dim3(persistent_grid_conn(r)), dim3(BLOCK), 0, st,
                                    r->bvh, r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1);
         } else {
             // grid-stride over the (device-side) ray count; enough workgroups to fill 256 CUs several times over
@@ -295,6 +313,7 @@ int launch_accumulate(cl2_renderer* r, hipStream_t st) {
 
 int need_scene(cl2_renderer* r) {
     if (!r) return CL2_E_INVALID;
+    r->pipe_active = false;
     if (!r->scene_ok) return fail(r, CL2_E_STATE, "no scene uploaded (call cl2_upload_scene first)");
     HIP_TRY(r, hipSetDevice(r->device));
     return CL2_OK;
@@ -600,6 +619,7 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     r->bvh.lds_tris = n_tris <= LDS_TRI_CAP ? 1 : 0;
     r->n_mats = n_mats; r->light_count = light_count; r->cam = cam;
     r->scene_ok = true;
+    r->paths_share = 0;                  // re-tune the stage shares for the new scene
     return CL2_OK;
 }
 
@@ -652,12 +672,10 @@ int cl2_process_images(cl2_renderer* r) {
  * streaming kernels leave the VALUs idle and the resolve kernel the memory system: the other stages'
  * workgroups fill what is left.  Each kernel sees exactly the inputs it would see in the serial
  * order (sums into the accumulators stay in sample order on stream_res), so results do not change. */
-int cl2_run_samples(cl2_renderer* r, int n) {
-    STAGE_PROLOGUE(r);
-    if (n < 0) return fail(r, CL2_E_INVALID, "negative sample count");
-    const bool pipe = r->pipelining != 0 && n > 1;
-    const int first_set = r->cur;
-    for (int i = 0; i < n; i++) {
+namespace {
+// Samples [i0, i1) of a cl2_run_samples call; `i` counts from the start of the call (buffer rotation).
+int enqueue_samples(cl2_renderer* r, bool pipe, int first_set, int i0, int i1) {
+    for (int i = i0; i < i1; i++) {
         const int ps = pipe ? (first_set + i) % 3 : r->cur, cs = pipe ? (i & 1) : 0;
         const PathBufs* set = r->sets[ps];
         hipStream_t s_conn = pipe ? r->stream_conn : r->stream;
@@ -687,6 +705,37 @@ int cl2_run_samples(cl2_renderer* r, int n) {
         // bound the number of in-flight event pairs while profiling
         if (r->profiling && r->spans.size() > 4096) TRY(drain(r));
     }
+    return CL2_OK;
+}
+}  // namespace
+
+int cl2_run_samples(cl2_renderer* r, int n) {
+    STAGE_PROLOGUE(r);
+    if (n < 0) return fail(r, CL2_E_INVALID, "negative sample count");
+    const bool pipe = r->pipelining != 0 && n > 1;
+    const int first_set = r->cur;
+    r->pipe_active = pipe;
+    int done = 0;
+    // Large scenes: the two stages share the machine's wave slots in a fixed ratio while the
+    // pipeline runs (persistent_grid_paths/_conn).  The best ratio depends on the scene (how the
+    // work splits between subpath and connection rays); it is found once per scene by timing three
+    // candidates on the first samples of a long enough call.  Every ratio renders the same samples.
+    if (pipe && split_mode(r) && r->paths_share == 0 && n >= 3 * TUNE_SAMPLES + TUNE_SAMPLES) {
+        int best = 4;
+        double best_t = 1e300;
+        for (int e = 3; e <= 5; e++) {
+            r->paths_share = e;
+            const auto t0 = std::chrono::steady_clock::now();
+            TRY(enqueue_samples(r, pipe, first_set, done, done + TUNE_SAMPLES));
+            TRY(drain(r));
+            const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            done += TUNE_SAMPLES;
+            if (t < best_t) { best_t = t; best = e; }
+        }
+        r->paths_share = best;
+    }
+    TRY(enqueue_samples(r, pipe, first_set, done, n));
+    r->pipe_active = false;
     TRY(drain(r));
     if (pipe && n > 0) r->cur = (first_set + n - 1) % 3;         // exports show the last sample's subpaths
     return CL2_OK;
@@ -805,6 +854,7 @@ int cl2_set_traversal_mode(cl2_renderer* r, int mode) {
     if (!r) return CL2_E_INVALID;
     if (mode < 0 || mode > 2) return fail(r, CL2_E_INVALID, "traversal mode must be 0 (auto), 1 (fused) or 2 (split)");
     r->traversal_mode = mode;
+    r->paths_share = 0;
     return CL2_OK;
 }
 int cl2_set_debug_flags(cl2_renderer* r, int flags) { if (!r) return CL2_E_INVALID; r->debug_flags = flags; return CL2_OK; }
