@@ -228,6 +228,7 @@ def main():
                          "avg_launch_ms": round(k_ms / max(k_launches, 1), 4),
                          # the same launch with nothing beside it (serial breakdown pass below)
                          "avg_launch_ms_serial": round(cb["ms_traverse_conn"] / max(cb["launches_traverse_conn"], 1), 4),
+                         "frac_serial": round((cb["rays_traverse_conn"] * b_ray) / max(cb["ms_traverse_conn"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
                          "sample_pipeline_stages": args.pipelining},
             "stage_ms_per_step_serial": stages,
         }
