@@ -1,6 +1,6 @@
 import csv, collections, glob, sys
 def load(d):
-    f = glob.glob(f"{d}/runc/*_counter_collection.csv")[0]
+    f = glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ","").replace("cl2::","")
