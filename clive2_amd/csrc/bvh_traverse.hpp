@@ -208,31 +208,11 @@ __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhVi
         }
         if (!__any(active)) break;
 
-        // ---- one step per live lane ----
+        // ---- one step per live lane: at most one node visit, then at most one triangle test (a lane
+        // that has just entered a leaf tests its first triangle in the same step), then retire ----
         const bool all_fast = __all(!active || fast);
         if (active) {
-            if (tri_i < tri_end) {
-                // one triangle of the current leaf: ray_triangle_intersect, trace.metal:117-142
-                const int i = tri_i++;
-                float4 a0, a1, a2;
-                if (b.lds_tris) { a0 = s.tris[3 * i]; a1 = s.tris[3 * i + 1]; a2 = s.tris[3 * i + 2]; }
-                else { a0 = b.tris[3 * i]; a1 = b.tris[3 * i + 1]; a2 = b.tris[3 * i + 2]; }
-                if (COUNT) n_tri++;
-                const V3 e1 = v3(a1), e2 = v3(a2);
-                const V3 h = cross(d, e2);
-                const float a = dot(e1, h);
-                const float f = rcp_exact(a);
-                const V3 sv = o - v3(a0);
-                const float u = f * dot(sv, h);
-                if (!(u < 0 || u > 1)) {
-                    const V3 q = cross(sv, e1);
-                    const float v = f * dot(d, q);
-                    if (!(v < 0 || u + v > 1)) {
-                        const float t = f * dot(e2, q);
-                        if (t > DELTA_F && t < best.t) { best.tri = i; best.t = t; best.u = u; best.v = v; }
-                    }
-                }
-            } else if (node < n_nodes) {
+            if (tri_i >= tri_end && node < n_nodes) {
                 // one node: ray_box_intersect + descend / skip (trace.metal:150-160)
                 float4 lo, hi;
                 if (node < b.n_lds_nodes) { lo = s.nodes[2 * node]; hi = s.nodes[2 * node + 1]; }
@@ -256,7 +236,30 @@ __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhVi
                     if (info < 0) node = ~info;
                     else { tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
                 }
-            } else {
+            }
+            if (tri_i < tri_end) {
+                // one triangle of the current leaf: ray_triangle_intersect, trace.metal:117-142
+                const int i = tri_i++;
+                float4 a0, a1, a2;
+                if (b.lds_tris) { a0 = s.tris[3 * i]; a1 = s.tris[3 * i + 1]; a2 = s.tris[3 * i + 2]; }
+                else { a0 = b.tris[3 * i]; a1 = b.tris[3 * i + 1]; a2 = b.tris[3 * i + 2]; }
+                if (COUNT) n_tri++;
+                const V3 e1 = v3(a1), e2 = v3(a2);
+                const V3 h = cross(d, e2);
+                const float a = dot(e1, h);
+                const float f = rcp_exact(a);
+                const V3 sv = o - v3(a0);
+                const float u = f * dot(sv, h);
+                if (!(u < 0 || u > 1)) {
+                    const V3 q = cross(sv, e1);
+                    const float v = f * dot(d, q);
+                    if (!(v < 0 || u + v > 1)) {
+                        const float t = f * dot(e2, q);
+                        if (t > DELTA_F && t < best.t) { best.tri = i; best.t = t; best.u = u; best.v = v; }
+                    }
+                }
+            }
+            if (tri_i >= tri_end && node >= n_nodes) {
                 src.store(key, best);
                 active = false;
             }
