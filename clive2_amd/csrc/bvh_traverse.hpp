@@ -159,7 +159,7 @@ namespace cl2 {
 
 constexpr int RAY_CHUNK_MAX = 512;  // rays handed to a wave per global atomic: 64..512, about a quarter of a wave's fair share
 
-template <bool COUNT, class Source>
+template <bool COUNT, bool TWO_TRIS, class Source>
 __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhView& b, unsigned n, unsigned* work_counter,
                                                     const Source& src, unsigned& n_box, unsigned& n_tri) {
     const int lane = threadIdx.x & 63;
@@ -238,24 +238,50 @@ __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhVi
                 }
             }
             if (tri_i < tri_end) {
-                // one triangle of the current leaf: ray_triangle_intersect, trace.metal:117-142
-                const int i = tri_i++;
-                float4 a0, a1, a2;
-                if (b.lds_tris) { a0 = s.tris[3 * i]; a1 = s.tris[3 * i + 1]; a2 = s.tris[3 * i + 2]; }
-                else { a0 = b.tris[3 * i]; a1 = b.tris[3 * i + 1]; a2 = b.tris[3 * i + 2]; }
-                if (COUNT) n_tri++;
-                const V3 e1 = v3(a1), e2 = v3(a2);
-                const V3 h = cross(d, e2);
-                const float a = dot(e1, h);
-                const float f = rcp_exact(a);
-                const V3 sv = o - v3(a0);
-                const float u = f * dot(sv, h);
-                if (!(u < 0 || u > 1)) {
-                    const V3 q = cross(sv, e1);
-                    const float v = f * dot(d, q);
-                    if (!(v < 0 || u + v > 1)) {
-                        const float t = f * dot(e2, q);
-                        if (t > DELTA_F && t < best.t) { best.tri = i; best.t = t; best.u = u; best.v = v; }
+                // one triangle of the current leaf -- two when TWO_TRIS (both fetched together, tested in order; pays
+                // while the tree is cache-resident and the step is issue-bound, not when it streams from memory):
+                // ray_triangle_intersect, trace.metal:117-142
+                const int i0 = tri_i;
+                const bool two = TWO_TRIS && i0 + 1 < tri_end;
+                const int i1 = two ? i0 + 1 : i0;
+                tri_i = i1 + 1;
+                float4 a0, a1, a2, c0, c1, c2;
+                if (b.lds_tris) {
+                    a0 = s.tris[3 * i0]; a1 = s.tris[3 * i0 + 1]; a2 = s.tris[3 * i0 + 2];
+                    if (TWO_TRIS) { c0 = s.tris[3 * i1]; c1 = s.tris[3 * i1 + 1]; c2 = s.tris[3 * i1 + 2]; }
+                } else {
+                    a0 = b.tris[3 * i0]; a1 = b.tris[3 * i0 + 1]; a2 = b.tris[3 * i0 + 2];
+                    if (TWO_TRIS) { c0 = b.tris[3 * i1]; c1 = b.tris[3 * i1 + 1]; c2 = b.tris[3 * i1 + 2]; }
+                }
+                if (COUNT) n_tri += two ? 2 : 1;
+                {
+                    const V3 e1 = v3(a1), e2 = v3(a2);
+                    const V3 h = cross(d, e2);
+                    const float f = rcp_exact(dot(e1, h));
+                    const V3 sv = o - v3(a0);
+                    const float u = f * dot(sv, h);
+                    if (!(u < 0 || u > 1)) {
+                        const V3 q = cross(sv, e1);
+                        const float v = f * dot(d, q);
+                        if (!(v < 0 || u + v > 1)) {
+                            const float t = f * dot(e2, q);
+                            if (t > DELTA_F && t < best.t) { best.tri = i0; best.t = t; best.u = u; best.v = v; }
+                        }
+                    }
+                }
+                if (TWO_TRIS && two) {
+                    const V3 e1 = v3(c1), e2 = v3(c2);
+                    const V3 h = cross(d, e2);
+                    const float f = rcp_exact(dot(e1, h));
+                    const V3 sv = o - v3(c0);
+                    const float u = f * dot(sv, h);
+                    if (!(u < 0 || u > 1)) {
+                        const V3 q = cross(sv, e1);
+                        const float v = f * dot(d, q);
+                        if (!(v < 0 || u + v > 1)) {
+                            const float t = f * dot(e2, q);
+                            if (t > DELTA_F && t < best.t) { best.tri = i1; best.t = t; best.u = u; best.v = v; }
+                        }
                     }
                 }
             }

@@ -214,7 +214,7 @@ struct ConnRaySource {          // connection rays: tag {slot, pixel} -> light v
     }
 };
 
-template <bool COUNT, class Source>
+template <bool COUNT, bool TWO_TRIS, class Source>
 __global__ __launch_bounds__(BLOCK) void k_traverse_persistent(BvhView bvh, const unsigned* __restrict__ count,
                                                               unsigned* __restrict__ work_counter, Source src, Stats* stats,
                                                               int is_conn) {
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_persistent(BvhView bvh, cons
     stage_bvh(lds, bvh);
     const unsigned n = *count;
     unsigned nb = 0, nt = 0;
-    traverse_persistent<COUNT>(lds, bvh, n, work_counter, src, nb, nt);
+    traverse_persistent<COUNT, TWO_TRIS>(lds, bvh, n, work_counter, src, nb, nt);
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) { nb += __shfl_down(nb, off); nt += __shfl_down(nt, off); }
         if (lane_id() == 0) {

@@ -178,6 +178,14 @@ inline bool split_mode(const cl2_renderer* r) {
     const bool all_lds = r->bvh.lds_tris && r->bvh.n_nodes <= r->bvh.n_lds_nodes;
     return r->traversal_mode == 2 || (r->traversal_mode == 0 && !all_lds);
 }
+// Two triangles per step of the persistent walk while the tree is cache-resident (the step is then
+// issue-bound and fewer, fatter steps win: glass +5 %, blob +4 %); one when it streams from memory
+// (1M triangles: two cost 3 %).  debug_flags bit 12 inverts the choice (tests run both forms).
+inline bool two_tris_per_step(const cl2_renderer* r) {
+    const size_t bytes = (size_t)r->bvh.n_nodes * 32 + (size_t)r->bvh.n_tris * 48;
+    const bool two = bytes <= ((size_t)16 << 20);
+    return ((r->debug_flags >> 12) & 1) ? !two : two;
+}
 inline int persistent_grid() { return 256 * 8; }      // 256 CUs x 8 workgroups of 4 waves = 32 waves per CU
 // While the sample pipeline runs, the subpath stage and the connection stage of two samples are on the
 // machine together.  Persistent launches hold their wave slots until the launch runs dry, so the two
@@ -214,12 +222,12 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
         if (split) {
             Timed t(r, ST_TRAVERSE_PATHS, st);
             PathRaySource src{q_in, pb.P0 + (size_t)first * B, pb.P1 + (size_t)first * B, r->d_hit};
-            if (r->counting)
-                hipLaunchKernelGGL((k_traverse_persistent<true, PathRaySource>), dim3(persistent_grid_paths(r)), dim3(BLOCK), 0, st,
-                                   r->bvh, c_in, r->d_work + first, src, r->d_stats, 0);
-            else
-                hipLaunchKernelGGL((k_traverse_persistent<false, PathRaySource>), dim3(persistent_grid_paths(r)), dim3(BLOCK), 0, st,
-                                   r->bvh, c_in, r->d_work + first, src, r->d_stats, 0);
+#define CL2_PERSIST(CNT, TWO)                                                                                              \
+            hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, PathRaySource>), dim3(persistent_grid_paths(r)), dim3(BLOCK), 0, \
+                               st, r->bvh, c_in, r->d_work + first, src, r->d_stats, 0)
+            if (two_tris_per_step(r)) { if (r->counting) CL2_PERSIST(true, true); else CL2_PERSIST(false, true); }
+            else { if (r->counting) CL2_PERSIST(true, false); else CL2_PERSIST(false, false); }
+#undef CL2_PERSIST
             r->launches_tp++;
             HIP_TRY(r, hipGetLastError());
         }
@@ -256,12 +264,12 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
             HIP_TRY(r, hipMemsetAsync(r->d_work + 7, 0, sizeof(unsigned), st));
             ConnRaySource src{r->d_ctag, lp.P0, cp.P0, r->d_chit[cs],
                               V3{r->cam.focal_point[0], r->cam.focal_point[1], r->cam.focal_point[2]}, B};
-            if (r->counting)
-                hipLaunchKernelGGL((k_traverse_persistent<true, ConnRaySource>), dim3(persistent_grid_conn(r)), dim3(BLOCK), 0, st,
-                                   r->bvh, r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1);
-            else
-                hipLaunchKernelGGL((k_traverse_persistent<false, ConnRaySource>), dim3(persistent_grid_conn(r)), dim3(BLOCK), 0, st,
-                                   r->bvh, r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1);
+#define CL2_PERSIST(CNT, TWO)                                                                                             \
+            hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, ConnRaySource>), dim3(persistent_grid_conn(r)), dim3(BLOCK), 0, \
+                               st, r->bvh, r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1)
+            if (two_tris_per_step(r)) { if (r->counting) CL2_PERSIST(true, true); else CL2_PERSIST(false, true); }
+            else { if (r->counting) CL2_PERSIST(true, false); else CL2_PERSIST(false, false); }
+#undef CL2_PERSIST
         } else {
             // grid-stride over the (device-side) ray count; enough workgroups to fill 256 CUs several times over
             const int grid = std::min<size_t>(grid_for((size_t)B * 8), 256 * 32);

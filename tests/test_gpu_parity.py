@@ -155,13 +155,17 @@ def test_levels_per_launch_is_a_pure_performance_knob(levels, glass_scene, oracl
         r.set_levels_per_launch(0)
 
 
+@pytest.mark.parametrize("flags", [0, 1 << 12])
 @pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
-def test_persistent_traversal_mode_is_equivalent(scene_name, request, oracle_mod):
+def test_persistent_traversal_mode_is_equivalent(scene_name, flags, request, oracle_mod):
     """traversal_mode 2 (persistent launches with lane-level ray replacement + one bounce launch per
-    level, the large-scene organisation) reproduces the oracle exactly, like the fused mode."""
+    level, the large-scene organisation) reproduces the oracle exactly, like the fused mode -- in
+    both forms of its step (two triangles per step for cache-resident trees, bit 12 selects the
+    one-triangle form used for trees that stream from memory)."""
     scene = request.getfixturevalue(scene_name)
     r, o = _pair(scene, oracle_mod)
     r.set_traversal_mode(2)
+    r.set_debug_flags(flags)
     _run_to_paths(r, o)
     for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
         assert r.export_paths(which).tobytes() == ref.tobytes()
