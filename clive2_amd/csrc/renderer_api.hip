@@ -191,16 +191,21 @@ inline int persistent_grid() { return 256 * 8; }      // 256 CUs x 8 workgroups 
 // machine together.  Persistent launches hold their wave slots until the launch runs dry, so the two
 // stages get a fixed share of the slots each (in eighths of the machine): the stage whose launch is in
 // its tail (a few long rays) leaves the VALUs to the other one instead of leaving them idle.
-constexpr int TUNE_SAMPLES = 6;       // samples timed per candidate share
+constexpr int TUNE_SAMPLES = 6;       // samples timed per candidate organisation
+constexpr int SHARE_SERIAL = 9;       // tuned result: the serial order beats every pipelined organisation
 inline int paths_eighths(const cl2_renderer* r) {
     const int forced = (r->debug_flags >> 8) & 7;          // experiment switch
-    return forced ? forced : (r->paths_share ? r->paths_share : 4);
+    return forced ? forced : ((r->paths_share && r->paths_share != SHARE_SERIAL) ? r->paths_share : 4);
 }
+// share 8 = no fixed shares: both stages launch full-size grids and take the slots as they come
+// (large frames: the launches are long, their tails do not matter, and a full grid hides latency best)
 inline int persistent_grid_paths(const cl2_renderer* r) {
-    return r->pipe_active ? 256 * paths_eighths(r) : persistent_grid();
+    const int e = paths_eighths(r);
+    return (r->pipe_active && e < 8) ? 256 * e : persistent_grid();
 }
 inline int persistent_grid_conn(const cl2_renderer* r) {
-    return r->pipe_active ? 256 * (8 - paths_eighths(r)) : persistent_grid();
+    const int e = paths_eighths(r);
+    return (r->pipe_active && e < 8) ? 256 * (8 - e) : persistent_grid();
 }
 
 // Subpath phase scratch (d_queue, d_qcount[0..6], d_work[0..6], d_hit, d_block_stats) is touched by this
@@ -681,9 +686,12 @@ int cl2_process_images(cl2_renderer* r) {
  * workgroups fill what is left.  Each kernel sees exactly the inputs it would see in the serial
  * order (sums into the accumulators stay in sample order on stream_res), so results do not change. */
 namespace {
-// Samples [i0, i1) of a cl2_run_samples call; `i` counts from the start of the call (buffer rotation).
-int enqueue_samples(cl2_renderer* r, bool pipe, int first_set, int i0, int i1) {
-    for (int i = i0; i < i1; i++) {
+// `count` samples, serial (one stream, the current buffer set) or pipelined (rotating sets, starting with
+// the current one); ends with everything complete and `cur` = the set of the last sample.
+int run_chunk(cl2_renderer* r, bool pipe, int count) {
+    const int first_set = r->cur;
+    r->pipe_active = pipe;
+    for (int i = 0; i < count; i++) {
         const int ps = pipe ? (first_set + i) % 3 : r->cur, cs = pipe ? (i & 1) : 0;
         const PathBufs* set = r->sets[ps];
         hipStream_t s_conn = pipe ? r->stream_conn : r->stream;
@@ -713,6 +721,9 @@ int enqueue_samples(cl2_renderer* r, bool pipe, int first_set, int i0, int i1) {
         // bound the number of in-flight event pairs while profiling
         if (r->profiling && r->spans.size() > 4096) TRY(drain(r));
     }
+    r->pipe_active = false;
+    TRY(drain(r));
+    if (pipe && count > 0) r->cur = (first_set + count - 1) % 3;
     return CL2_OK;
 }
 }  // namespace
@@ -720,33 +731,29 @@ int enqueue_samples(cl2_renderer* r, bool pipe, int first_set, int i0, int i1) {
 int cl2_run_samples(cl2_renderer* r, int n) {
     STAGE_PROLOGUE(r);
     if (n < 0) return fail(r, CL2_E_INVALID, "negative sample count");
-    const bool pipe = r->pipelining != 0 && n > 1;
-    const int first_set = r->cur;
-    r->pipe_active = pipe;
+    bool pipe = r->pipelining != 0 && n > 1;
     int done = 0;
-    // Large scenes: the two stages share the machine's wave slots in a fixed ratio while the
-    // pipeline runs (persistent_grid_paths/_conn).  The best ratio depends on the scene (how the
-    // work splits between subpath and connection rays); it is found once per scene by timing three
-    // candidates on the first samples of a long enough call.  Every ratio renders the same samples.
-    if (pipe && split_mode(r) && r->paths_share == 0 && n >= 3 * TUNE_SAMPLES + TUNE_SAMPLES) {
+    // Large scenes: while the pipeline runs the two stages share the machine's wave slots in a fixed
+    // ratio (persistent_grid_paths/_conn).  The best organisation depends on the scene and the frame size
+    // (how the work splits between subpath and connection rays, how long the launches are); it is
+    // found once per scene by timing the candidates -- 3, 4, 5 eighths for the subpath stage, no
+    // fixed shares, serial order -- on the first samples of a long enough call.  All of them render
+    // the same samples.
+    if (pipe && split_mode(r) && r->paths_share == 0 && n >= 6 * TUNE_SAMPLES) {
         int best = 4;
         double best_t = 1e300;
-        for (int e = 3; e <= 5; e++) {
+        for (int e : {3, 4, 5, 8, SHARE_SERIAL}) {
             r->paths_share = e;
             const auto t0 = std::chrono::steady_clock::now();
-            TRY(enqueue_samples(r, pipe, first_set, done, done + TUNE_SAMPLES));
-            TRY(drain(r));
+            TRY(run_chunk(r, e != SHARE_SERIAL, TUNE_SAMPLES));
             const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             done += TUNE_SAMPLES;
             if (t < best_t) { best_t = t; best = e; }
         }
         r->paths_share = best;
     }
-    TRY(enqueue_samples(r, pipe, first_set, done, n));
-    r->pipe_active = false;
-    TRY(drain(r));
-    if (pipe && n > 0) r->cur = (first_set + n - 1) % 3;         // exports show the last sample's subpaths
-    return CL2_OK;
+    if (pipe && split_mode(r) && r->paths_share == SHARE_SERIAL) pipe = false;
+    return run_chunk(r, pipe, n - done);
 }
 
 int cl2_set_pipelining(cl2_renderer* r, int on) {
