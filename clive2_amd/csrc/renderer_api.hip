@@ -49,7 +49,7 @@ struct cl2_renderer {
     hipEvent_t ev_paths[3] = {}, ev_conn[2] = {}, ev_res[6] = {};
     bool pipe_active = false;            // inside a pipelined cl2_run_samples
     int paths_share = 0;                 // eighths of the wave slots given to the subpath stage while pipelining (0 = not tuned yet)
-    int pipelining = 1;                  // sample pipeline inside cl2_run_samples: 0 serial, 1 two stages, 2 three stages
+    int pipelining = -1;                 // sample pipeline inside cl2_run_samples: 0 serial, 1 two stages, 2 three stages, -1 by frame size
     std::string err;
     bool scene_ok = false, counting = false;
     int profiling = 0;                   // 0 off, 1 the connection-ray traversal launch only, 2 every stage
@@ -185,6 +185,13 @@ inline bool two_tris_per_step(const cl2_renderer* r) {
     const size_t bytes = (size_t)r->bvh.n_nodes * 32 + (size_t)r->bvh.n_tris * 48;
     const bool two = bytes <= ((size_t)16 << 20);
     return ((r->debug_flags >> 12) & 1) ? !two : two;
+}
+// Stages of the sample pipeline.  Small frames do not fill the machine with one launch (256x256: 256
+// workgroups on 256 CUs), so a third stage side by side pays (10.1 / 13.9 / 18.4 Grays/s with 0 / 1 / 2);
+// from 1080p on two and three stages measure the same and two need less memory traffic in flight.
+inline int pipeline_stages(const cl2_renderer* r) {
+    if (r->pipelining >= 0) return r->pipelining;
+    return r->B <= (1 << 19) ? 2 : 1;
 }
 inline int persistent_grid() { return 256 * 8; }      // 256 CUs x 8 workgroups of 4 waves = 32 waves per CU
 // While the sample pipeline runs, the subpath stage and the connection stage of two samples are on the
@@ -695,7 +702,7 @@ int run_chunk(cl2_renderer* r, bool pipe, int count) {
         const int ps = pipe ? (first_set + i) % 3 : r->cur, cs = pipe ? (i & 1) : 0;
         const PathBufs* set = r->sets[ps];
         hipStream_t s_conn = pipe ? r->stream_conn : r->stream;
-        hipStream_t s_res = pipe ? (r->pipelining == 2 ? r->stream_res : r->stream_conn) : r->stream;
+        hipStream_t s_res = pipe ? (pipeline_stages(r) == 2 ? r->stream_res : r->stream_conn) : r->stream;
         // resolve of sample i-3 was the last reader of this subpath set
         if (pipe && i >= 3) HIP_TRY(r, hipStreamWaitEvent(r->stream, r->ev_res[(i - 3) % 6], 0));
         TRY(launch_generate(r, CL2_LIGHT, r->stream, set));
@@ -731,7 +738,7 @@ int run_chunk(cl2_renderer* r, bool pipe, int count) {
 int cl2_run_samples(cl2_renderer* r, int n) {
     STAGE_PROLOGUE(r);
     if (n < 0) return fail(r, CL2_E_INVALID, "negative sample count");
-    bool pipe = r->pipelining != 0 && n > 1;
+    bool pipe = pipeline_stages(r) != 0 && n > 1;
     int done = 0;
     // Large scenes: while the pipeline runs the two stages share the machine's wave slots in a fixed
     // ratio (persistent_grid_paths/_conn).  The best organisation depends on the scene and the frame size
@@ -758,7 +765,7 @@ int cl2_run_samples(cl2_renderer* r, int n) {
 
 int cl2_set_pipelining(cl2_renderer* r, int on) {
     if (!r) return CL2_E_INVALID;
-    if (on < 0 || on > 2) return fail(r, CL2_E_INVALID, "pipelining must be 0..2");
+    if (on < -1 || on > 2) return fail(r, CL2_E_INVALID, "pipelining must be -1..2");
     r->pipelining = on;
     return CL2_OK;
 }

@@ -230,9 +230,10 @@ class Renderer:
         self._check(self._L.cl2_selftest_exact_math(self._h, C.byref(a), C.byref(b)), "selftest_exact_math")
         return a.value, b.value
 
-    def set_pipelining(self, stages=1):
-        """Sample pipeline inside run_samples: 0 serial, 1 (default) subpaths of sample i+1 beside the
-        connection phase of sample i, 2 three stages.  A pure performance knob, results are identical."""
+    def set_pipelining(self, stages=-1):
+        """Sample pipeline inside run_samples: 0 serial, 1 subpaths of sample i+1 beside the connection
+        phase of sample i, 2 three stages, -1 (default) chosen by frame size.  A pure performance knob,
+        results are identical."""
         self._check(self._L.cl2_set_pipelining(self._h, int(stages)), "set_pipelining")
 
     def set_traversal_mode(self, mode):

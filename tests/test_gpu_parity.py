@@ -425,3 +425,4 @@ def test_sample_pipeline_is_a_pure_performance_knob(mode, glass_scene, oracle_mo
     assert r1.read_accumulators()[3].tobytes() == r2.read_accumulators()[3].tobytes() == r3.read_accumulators()[3].tobytes()
     with pytest.raises(Exception):
         r1.set_pipelining(3)
+    r1.set_pipelining(-1)                      # by frame size (the default)
