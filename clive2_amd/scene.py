@@ -55,10 +55,13 @@ class Scene:
 
 
 def create_scene(pixel_width=1280, pixel_height=720, cam_center=ZERO_VECTOR, cam_direction=UNIT_Z,
-                 file_specs=None, materials=None, verbose=False, bvh_builder="auto"):
+                 file_specs=None, materials=None, verbose=False, bvh_builder="auto", room=None):
+    """scene.py:21-104.  Extensions: `materials` (table override), `"mesh": (vertices, faces)` file specs,
+    `bvh_builder`, and `room` -- the enclosure as a list of load.Triangle objects in place of the
+    Cornell box of load.triangles_for_box() (e.g. a subset of it: an open scene; it must keep an emitter)."""
     camera = Camera(center=cam_center, direction=cam_direction, pixel_width=pixel_width,
                     pixel_height=pixel_height, phys_width=pixel_width / pixel_height, phys_height=1)
-    soups = [FastTreeBox.from_triangle_objects(camera_geometry(camera) + triangles_for_box())]
+    soups = [FastTreeBox.from_triangle_objects(camera_geometry(camera) + (triangles_for_box() if room is None else list(room)))]
     for spec in file_specs or ():
         kw = dict(material=spec.get("material", 0), scale=spec.get("scale", 1.0),
                   offset=spec.get("offset", ZERO_VECTOR))

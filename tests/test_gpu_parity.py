@@ -426,3 +426,39 @@ def test_sample_pipeline_is_a_pure_performance_knob(mode, glass_scene, oracle_mo
     with pytest.raises(Exception):
         r1.set_pipelining(3)
     r1.set_pipelining(-1)                      # by frame size (the default)
+
+
+@pytest.mark.parametrize("mode,levels,stages", [(1, 6, 0), (1, 2, 1), (2, 1, 2), (1, 1, 2)])
+def test_open_scene_paths_of_every_length(mode, levels, stages, oracle_mod):
+    """An OPEN scene (floor, back wall, emitter and a glass ball; no other walls): most subpaths leave
+    the scene after one to three bounces, so every subpath length occurs, queues shrink from level to
+    level (compaction between launches, persistent launches that run dry early) and most (t,s) pairs
+    do not exist.  Subpaths, seeds, aggregators and the accumulated image against the oracle."""
+    import clive2_amd as c2
+    from clive2_amd.load import triangles_for_box
+    from clive2_amd.meshes import icosphere
+    box = triangles_for_box()
+    keep = [t for t in box if t.emitter or t.n[1] > 0.5 or t.n[2] > 0.5]          # emitter, floor, back wall
+    assert len(keep) == 6
+    scene = c2.create_scene(72, 40, np.array([0, 1.5, 6.0]), np.array([0, 0, -1.0]), room=keep,
+                            file_specs=[dict(mesh=icosphere(2, radius=1.5), material=5, offset=np.array([0.5, 0.0, -1.0]))])
+    r, o = _pair(scene, oracle_mod)
+    r.set_traversal_mode(mode); r.set_levels_per_launch(levels); r.set_pipelining(stages)
+    _run_to_paths(r, o)
+    for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
+        assert r.export_paths(which).tobytes() == ref.tobytes()
+    lens = np.bincount(o.out_camera_paths["length"], minlength=7)
+    assert (lens[1:] > 0).all(), lens                         # every camera subpath length 1..6 occurs
+    assert np.bincount(o.out_light_paths["length"], minlength=7)[:4].sum() > 0.3 * len(o.out_light_paths)
+    _run_rest(r, o)
+    agg = r.export_aggregators()
+    assert agg["total_contribution"].tobytes() == o.weight_aggregators["total_contribution"].tobytes()
+    assert agg["weights"].tobytes() == o.weight_aggregators["weights"].tobytes()
+    r.run_samples(3)
+    for _ in range(3):
+        o.run_sample()
+    assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
+    img, wts, cnt, uni = r.read_accumulators()
+    np.testing.assert_allclose(img, o.summed_image, rtol=5e-5, atol=1e-8)
+    np.testing.assert_allclose(wts, o.summed_sample_weights, rtol=5e-5, atol=1e-8)
+    assert r.counters()["rays"] == o.rays_traced
