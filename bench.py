@@ -75,7 +75,13 @@ def build_scene(name, W, H):
     from clive2_amd import meshes
     mats = get_materials()
     mats["alpha"][5] = 0.1                       # rough glass (the shipped table has alpha 0)
-    if name == "glass":
+    room = None
+    if name == "open":
+        from clive2_amd.load import triangles_for_box
+        room = [t for t in triangles_for_box() if t.emitter or t.n[1] > 0.5 or t.n[2] > 0.5]
+        specs = [dict(mesh=meshes.icosphere(2, radius=1.5), material=5, offset=np.array([0.5, 0.0, -1.0]))]
+        desc = "open scene: emitter, floor, back wall and a 320-tri glass ball (most subpaths leave after 1-3 bounces)"
+    elif name == "glass":
         specs = [dict(mesh=meshes.icosphere(4, radius=2.0, center=(0.0, 1.0, 0.0)), material=5)]
         desc = "Cornell box + 5,120-tri rough-glass icosphere (config 3 stand-in)"
     elif name == "blob":
@@ -84,7 +90,7 @@ def build_scene(name, W, H):
     else:
         specs = [dict(mesh=(v, f), material=m) for v, f, m in meshes.interior_grid()]
         desc = "Cornell box + 49 x 20,480-tri icospheres (config 5 stand-in)"
-    s = c2.create_scene(W, H, np.array([0, 1.5, 6]), np.array([0, 0, -1]), file_specs=specs, materials=mats)
+    s = c2.create_scene(W, H, np.array([0, 1.5, 6]), np.array([0, 0, -1]), file_specs=specs, materials=mats, room=room)
     return s, desc + f", {len(s.triangles)} tris / {len(s.boxes)} boxes"
 
 
@@ -97,10 +103,10 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-flags", type=int, default=0, help="performance experiments only (invalid renders)")
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "glass", "blob", "interior"],
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "glass", "blob", "interior", "open"],
                     help="cornell = the BASELINE metric's workload (default); the others are the mesh configs "
                          "(SURVEY 8d C3-C5 stand-ins), for profiling only")
-    ap.add_argument("--levels-per-launch", type=int, default=6, help="subpath bounces per launch (1..6)")
+    ap.add_argument("--levels-per-launch", type=int, default=0, help="subpath bounces per launch (1..6; 0 = by survival, the default)")
     ap.add_argument("--pipelining", type=int, default=-1, help="sample pipeline: 0 serial, 1 subpaths of sample i+1 beside the connection phase of sample i, 2 three stages, -1 by frame size (default)")
     ap.add_argument("--traversal-mode", type=int, default=0, help="0 auto, 1 fused, 2 persistent traversal with ray replacement")
     ap.add_argument("--cpu-width", type=int, default=1920)

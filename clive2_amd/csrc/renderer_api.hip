@@ -56,7 +56,8 @@ struct cl2_renderer {
     int debug_flags = 0;
     int traversal_mode = 0;              // 0 auto, 1 fused (one ray per lane), 2 split (persistent traversal + ray replacement)
     unsigned* d_work = nullptr;          // [8] work counters of the persistent traversal launches
-    int levels_per_launch = MAX_VERTS;   // subpath levels per launch (6 = one launch, 1 = compaction after every bounce)
+    int levels_per_launch = 0;           // subpath levels per launch (6 = one launch, 1 = compaction after every bounce, 0 = by survival)
+    int levels_auto = 0;                 // the choice made for levels_per_launch == 0 (0 = not made yet)
 
     // scene
     BvhView bvh{};
@@ -186,6 +187,10 @@ inline bool two_tris_per_step(const cl2_renderer* r) {
     const bool two = bytes <= ((size_t)16 << 20);
     return ((r->debug_flags >> 12) & 1) ? !two : two;
 }
+inline int effective_levels(const cl2_renderer* r) {
+    if (r->levels_per_launch > 0) return std::min(r->levels_per_launch, (int)MAX_VERTS);
+    return r->levels_auto ? r->levels_auto : (int)MAX_VERTS;
+}
 // Stages of the sample pipeline.  Small frames do not fill the machine with one launch (256x256: 256
 // workgroups on 256 CUs), so a third stage side by side pays (10.1 / 13.9 / 18.4 Grays/s with 0 / 1 / 2);
 // from 1080p on two and three stages measure the same and two need less memory traffic in flight.
@@ -223,7 +228,7 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
     HIP_TRY(r, hipMemsetAsync(r->d_qcount + 1, 0, 6 * sizeof(unsigned), st));
     const bool split = split_mode(r);
     if (split) HIP_TRY(r, hipMemsetAsync(r->d_work, 0, 7 * sizeof(unsigned), st));
-    const int step = split ? 1 : std::max(1, std::min(r->levels_per_launch, (int)MAX_VERTS));
+    const int step = split ? 1 : effective_levels(r);
     for (int first = 0; first < MAX_VERTS; first += step) {
         const int end = std::min(first + step, (int)MAX_VERTS);
         // queue slot k holds the paths alive after level k-1 (slot 0 = everybody, count B)
@@ -640,6 +645,7 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     r->n_mats = n_mats; r->light_count = light_count; r->cam = cam;
     r->scene_ok = true;
     r->paths_share = 0;                  // re-tune the stage shares for the new scene
+    r->levels_auto = 0;
     return CL2_OK;
 }
 
@@ -693,6 +699,17 @@ int cl2_process_images(cl2_renderer* r) {
  * workgroups fill what is left.  Each kernel sees exactly the inputs it would see in the serial
  * order (sums into the accumulators stay in sample order on stream_res), so results do not change. */
 namespace {
+// rays traced by the subpath kernels so far (per-workgroup slots, summed here)
+int subpath_ray_tally(cl2_renderer* r, unsigned long long* out) {
+    TRY(drain(r));
+    std::vector<unsigned long long> slots((size_t)grid_for(r->B) * 4);
+    HIP_TRY(r, hipMemcpy(slots.data(), r->d_block_stats, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long t = 0;
+    for (size_t b = 0; b < slots.size(); b += 4) t += slots[b];
+    *out = t;
+    return CL2_OK;
+}
+
 // `count` samples, serial (one stream, the current buffer set) or pipelined (rotating sets, starting with
 // the current one); ends with everything complete and `cur` = the set of the last sample.
 int run_chunk(cl2_renderer* r, bool pipe, int count) {
@@ -740,6 +757,19 @@ int cl2_run_samples(cl2_renderer* r, int n) {
     if (n < 0) return fail(r, CL2_E_INVALID, "negative sample count");
     bool pipe = pipeline_stages(r) != 0 && n > 1;
     int done = 0;
+    // Small scenes, levels_per_launch = 0: one whole-subpath launch keeps a wave busy as long as its
+    // longest path lives.  In a closed scene that is every path (6.0 rays per subpath: nothing to gain,
+    // compaction costs 35 %); in an open scene most paths leave after a bounce or two and a wave idles on
+    // its last survivor.  The first sample of a scene tells which: below 4 rays per subpath the walk is cut
+    // into launches of 2 bounces with the survivors compacted in between (open test scene: 2.02 -> 1.62 ms).
+    if (!split_mode(r) && r->levels_per_launch == 0 && r->levels_auto == 0 && n >= 2) {
+        unsigned long long before = 0, after = 0;
+        TRY(subpath_ray_tally(r, &before));
+        TRY(run_chunk(r, false, 1));
+        TRY(subpath_ray_tally(r, &after));
+        done = 1;
+        r->levels_auto = (double)(after - before) < 4.0 * 2.0 * (double)r->B ? 2 : (int)MAX_VERTS;
+    }
     // Large scenes: while the pipeline runs the two stages share the machine's wave slots in a fixed
     // ratio (persistent_grid_paths/_conn).  The best organisation depends on the scene and the frame size
     // (how the work splits between subpath and connection rays, how long the launches are); it is
@@ -819,7 +849,7 @@ int cl2_set_profiling(cl2_renderer* r, int level) {
 }
 int cl2_set_levels_per_launch(cl2_renderer* r, int levels) {
     if (!r) return CL2_E_INVALID;
-    if (levels < 1 || levels > MAX_VERTS) return fail(r, CL2_E_INVALID, "levels_per_launch must be 1..6");
+    if (levels < 0 || levels > MAX_VERTS) return fail(r, CL2_E_INVALID, "levels_per_launch must be 0 (by survival) or 1..6");
     r->levels_per_launch = levels;
     return CL2_OK;
 }

@@ -221,7 +221,8 @@ class Renderer:
         self._check(self._L.cl2_set_counting(self._h, int(bool(on))), "set_counting")
 
     def set_levels_per_launch(self, levels):
-        """Bounces traced per launch (1..6); a pure performance knob, results are identical."""
+        """Bounces traced per launch (1..6, 0 = chosen from the survival seen in the first sample); a pure
+        performance knob, results are identical."""
         self._check(self._L.cl2_set_levels_per_launch(self._h, int(levels)), "set_levels_per_launch")
 
     def selftest_exact_math(self):

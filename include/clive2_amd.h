@@ -102,9 +102,10 @@ int cl2_gather_light_image(cl2_renderer* r);
 int cl2_process_images(cl2_renderer* r);
 int cl2_run_samples(cl2_renderer* r, int n);
 
-/* Subpath levels (bounces) traced per launch: 6 (default) walks a whole subpath in one launch with
- * its state in registers; 1 compacts the survivors after every bounce (pays when most paths die
- * early: open scenes).  Results are identical for every setting. */
+/* Subpath levels (bounces) traced per launch: 6 walks a whole subpath in one launch with its state in
+ * registers; 1 compacts the survivors after every bounce (pays when most paths die early: open
+ * scenes); 0 (default) decides between 6 and 2 from the rays per subpath of the scene's first sample.
+ * Results are identical for every setting. */
 int cl2_set_levels_per_launch(cl2_renderer* r, int levels);
 /* Traversal organisation: 1 = one ray per lane inside the subpath / connection kernels (best when the
  * tree is LDS-resident), 2 = persistent traversal launches with lane-level ray replacement + one

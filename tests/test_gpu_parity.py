@@ -152,7 +152,7 @@ def test_levels_per_launch_is_a_pure_performance_knob(levels, glass_scene, oracl
     assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
     assert r.counters()["rays"] == o.rays_traced
     with pytest.raises(Exception):
-        r.set_levels_per_launch(0)
+        r.set_levels_per_launch(7)
 
 
 @pytest.mark.parametrize("flags", [0, 1 << 12])
@@ -428,7 +428,7 @@ def test_sample_pipeline_is_a_pure_performance_knob(mode, glass_scene, oracle_mo
     r1.set_pipelining(-1)                      # by frame size (the default)
 
 
-@pytest.mark.parametrize("mode,levels,stages", [(1, 6, 0), (1, 2, 1), (2, 1, 2), (1, 1, 2)])
+@pytest.mark.parametrize("mode,levels,stages", [(1, 6, 0), (1, 2, 1), (2, 1, 2), (1, 0, 2)])
 def test_open_scene_paths_of_every_length(mode, levels, stages, oracle_mod):
     """An OPEN scene (floor, back wall, emitter and a glass ball; no other walls): most subpaths leave
     the scene after one to three bounces, so every subpath length occurs, queues shrink from level to
