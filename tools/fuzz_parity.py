@@ -13,7 +13,7 @@ import numpy as np
 
 import clive2_amd as c2
 from clive2_amd import struct_types as st
-from clive2_amd.load import get_materials
+from clive2_amd.load import get_materials, triangles_for_box
 from clive2_amd.meshes import icosphere, noisy_blob
 from clive2_amd.renderer import Renderer, make_seeds
 from oracle import oracle as orc
@@ -40,7 +40,12 @@ def random_scene(rng):
     direction = np.array([-np.sin(theta), rng.choice([0.0, 0.0, -0.2, 0.15]), -np.cos(theta)])
     direction = direction / np.linalg.norm(direction)
     builder = rng.choice(["numpy", "native"])
-    return c2.create_scene(w, h, center, direction, file_specs=specs, materials=mats, bvh_builder=str(builder)), (w, h, len(specs), builder)
+    room = None
+    if rng.rand() < 0.3:                    # an open scene: the emitter and a random subset of the walls
+        box = triangles_for_box()
+        room = [t for t in box if t.emitter or rng.rand() < 0.5]
+    return (c2.create_scene(w, h, center, direction, file_specs=specs, materials=mats, bvh_builder=str(builder), room=room),
+            (w, h, len(specs), str(builder), 'open' if room is not None else 'closed'))
 
 
 def main():
@@ -54,7 +59,7 @@ def main():
         B = scene.pixel_width * scene.pixel_height
         seeds = make_seeds(B, seed=k)
         r, o = Renderer(scene, seeds=seeds), orc.OracleRenderer(scene, seeds=seeds)
-        mode, levels, stages = int(rng.randint(0, 3)), int(rng.randint(1, 7)), int(rng.randint(0, 3))
+        mode, levels, stages = int(rng.randint(0, 3)), int(rng.randint(0, 7)), int(rng.randint(-1, 3))
         r.set_traversal_mode(mode)
         r.set_levels_per_launch(levels)
         r.set_pipelining(stages)
