@@ -108,7 +108,7 @@ def main():
                          "(SURVEY 8d C3-C5 stand-ins), for profiling only")
     ap.add_argument("--levels-per-launch", type=int, default=0, help="subpath bounces per launch (1..6; 0 = by survival, the default)")
     ap.add_argument("--pipelining", type=int, default=-1, help="sample pipeline: 0 serial, 1 subpaths of sample i+1 beside the connection phase of sample i, 2 three stages, -1 by frame size (default)")
-    ap.add_argument("--traversal-mode", type=int, default=0, help="0 auto, 1 fused, 2 persistent traversal with ray replacement")
+    ap.add_argument("--traversal-mode", type=int, default=0, help="0 auto, 1 fused, 2 persistent traversal with ray replacement, 3 fused subpaths + persistent connection rays")
     ap.add_argument("--cpu-width", type=int, default=1920)
     ap.add_argument("--cpu-height", type=int, default=1080)
     ap.add_argument("--cpu-samples", type=int, default=4)

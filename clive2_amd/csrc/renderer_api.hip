@@ -173,11 +173,23 @@ int launch_generate(cl2_renderer* r, int which, hipStream_t st, const PathBufs* 
     return CL2_OK;
 }
 
-// Large scenes (tree not LDS-resident): traversal runs as its own persistent launch with lane-level
-// ray replacement, one bounce launch per level consumes its hits.
-inline bool split_mode(const cl2_renderer* r) {
-    const bool all_lds = r->bvh.lds_tris && r->bvh.n_nodes <= r->bvh.n_lds_nodes;
-    return r->traversal_mode == 2 || (r->traversal_mode == 0 && !all_lds);
+// Trees that are not LDS-resident.  Connection rays (one big launch of rays of very different cost)
+// run as a persistent launch with lane-level ray replacement.  Subpaths have two organisations:
+//   persistent (mode 2, the automatic choice)  one persistent traversal launch + one bounce launch per
+//               level: best lane use, but 24 small launches per sample, each ending in a tail;
+//   fused (mode 3)  the whole-subpath kernel of the small scenes, its tree fetched through the caches:
+//               one ray per lane (a wave is as slow as its slowest ray), but 2 launches and no tails.
+// In serial order fused wins on mid-size trees (5k-triangle sphere: 5.7 vs 8.7 ms per sample), but
+// the sample pipeline with stage shares hides the tails of the persistent form and then the two are
+// equal there (6.05 vs 6.00 Grays/s) and persistent wins from 82k triangles on (4.7 vs 3.9).
+inline bool tree_in_lds(const cl2_renderer* r) { return r->bvh.lds_tris && r->bvh.n_nodes <= r->bvh.n_lds_nodes; }
+inline bool split_paths(const cl2_renderer* r) {
+    if (r->traversal_mode == 1 || r->traversal_mode == 3) return false;
+    if (r->traversal_mode == 2) return true;
+    return !tree_in_lds(r);
+}
+inline bool split_conn(const cl2_renderer* r) {
+    return r->traversal_mode == 2 || r->traversal_mode == 3 || (r->traversal_mode == 0 && !tree_in_lds(r));
 }
 // Two triangles per step of the persistent walk while the tree is cache-resident (the step is then
 // issue-bound and fewer, fatter steps win: glass +5 %, blob +4 %); one when it streams from memory
@@ -226,7 +238,7 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
     const int B = r->B;
     PathBufs pb = set[which];
     HIP_TRY(r, hipMemsetAsync(r->d_qcount + 1, 0, 6 * sizeof(unsigned), st));
-    const bool split = split_mode(r);
+    const bool split = split_paths(r);
     if (split) HIP_TRY(r, hipMemsetAsync(r->d_work, 0, 7 * sizeof(unsigned), st));
     const int step = split ? 1 : effective_levels(r);
     for (int first = 0; first < MAX_VERTS; first += step) {
@@ -277,7 +289,7 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
     HIP_TRY(r, hipGetLastError());
     {
         Timed t(r, ST_TRAVERSE_CONN, st);
-        if (split_mode(r)) {
+        if (split_conn(r)) {
             HIP_TRY(r, hipMemsetAsync(r->d_work + 7, 0, sizeof(unsigned), st));
             ConnRaySource src{r->d_ctag, lp.P0, cp.P0, r->d_chit[cs],
                               V3{r->cam.focal_point[0], r->cam.focal_point[1], r->cam.focal_point[2]}, B};
@@ -762,7 +774,7 @@ int cl2_run_samples(cl2_renderer* r, int n) {
     // compaction costs 35 %); in an open scene most paths leave after a bounce or two and a wave idles on
     // its last survivor.  The first sample of a scene tells which: below 4 rays per subpath the walk is cut
     // into launches of 2 bounces with the survivors compacted in between (open test scene: 2.02 -> 1.62 ms).
-    if (!split_mode(r) && r->levels_per_launch == 0 && r->levels_auto == 0 && n >= 2) {
+    if (!split_paths(r) && r->levels_per_launch == 0 && r->levels_auto == 0 && n >= 2) {
         unsigned long long before = 0, after = 0;
         TRY(subpath_ray_tally(r, &before));
         TRY(run_chunk(r, false, 1));
@@ -770,26 +782,31 @@ int cl2_run_samples(cl2_renderer* r, int n) {
         done = 1;
         r->levels_auto = (double)(after - before) < 4.0 * 2.0 * (double)r->B ? 2 : (int)MAX_VERTS;
     }
-    // Large scenes: while the pipeline runs the two stages share the machine's wave slots in a fixed
-    // ratio (persistent_grid_paths/_conn).  The best organisation depends on the scene and the frame size
-    // (how the work splits between subpath and connection rays, how long the launches are); it is
-    // found once per scene by timing the candidates -- 3, 4, 5 eighths for the subpath stage, no
-    // fixed shares, serial order -- on the first samples of a long enough call.  All of them render
+    // Large scenes, first long call: how the two stages share the machine while the pipeline runs.
+    // Persistent launches hold their wave slots until they run dry, so the stages get fixed shares
+    // (persistent_grid_paths/_conn) -- 3, 4 or 5 eighths for the subpath stage, no fixed shares, or the
+    // serial order.  The best choice depends on the scene and the frame size; every candidate renders
     // the same samples.
-    if (pipe && split_mode(r) && r->paths_share == 0 && n >= 6 * TUNE_SAMPLES) {
+    auto timed_chunk = [&](bool pipelined, int count, double& seconds) -> int {
+        const auto t0 = std::chrono::steady_clock::now();
+        TRY(run_chunk(r, pipelined, count));
+        seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        done += count;
+        return CL2_OK;
+    };
+    const bool long_call = n - done >= 6 * TUNE_SAMPLES + 6;
+    if (pipe && split_conn(r) && r->paths_share == 0 && long_call) {
         int best = 4;
         double best_t = 1e300;
         for (int e : {3, 4, 5, 8, SHARE_SERIAL}) {
             r->paths_share = e;
-            const auto t0 = std::chrono::steady_clock::now();
-            TRY(run_chunk(r, e != SHARE_SERIAL, TUNE_SAMPLES));
-            const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            done += TUNE_SAMPLES;
+            double t = 0;
+            TRY(timed_chunk(e != SHARE_SERIAL, TUNE_SAMPLES, t));
             if (t < best_t) { best_t = t; best = e; }
         }
         r->paths_share = best;
     }
-    if (pipe && split_mode(r) && r->paths_share == SHARE_SERIAL) pipe = false;
+    if (pipe && split_conn(r) && r->paths_share == SHARE_SERIAL) pipe = false;
     return run_chunk(r, pipe, n - done);
 }
 
@@ -904,7 +921,7 @@ int cl2_probe_bounce(cl2_renderer* r, int from_camera, const float* in, size_t n
 }
 int cl2_set_traversal_mode(cl2_renderer* r, int mode) {
     if (!r) return CL2_E_INVALID;
-    if (mode < 0 || mode > 2) return fail(r, CL2_E_INVALID, "traversal mode must be 0 (auto), 1 (fused) or 2 (split)");
+    if (mode < 0 || mode > 3) return fail(r, CL2_E_INVALID, "traversal mode must be 0 (auto), 1 (fused), 2 (persistent) or 3 (fused subpaths, persistent connection rays)");
     r->traversal_mode = mode;
     r->paths_share = 0;
     return CL2_OK;

@@ -238,7 +238,8 @@ class Renderer:
         self._check(self._L.cl2_set_pipelining(self._h, int(stages)), "set_pipelining")
 
     def set_traversal_mode(self, mode):
-        """0 auto, 1 fused one-ray-per-lane kernels, 2 persistent traversal with ray replacement."""
+        """0 auto, 1 fused one-ray-per-lane kernels, 2 persistent traversal with ray replacement, 3 fused
+        subpaths + persistent connection rays."""
         self._check(self._L.cl2_set_traversal_mode(self._h, int(mode)), "set_traversal_mode")
 
     def set_debug_flags(self, flags):

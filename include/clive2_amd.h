@@ -109,8 +109,9 @@ int cl2_run_samples(cl2_renderer* r, int n);
 int cl2_set_levels_per_launch(cl2_renderer* r, int levels);
 /* Traversal organisation: 1 = one ray per lane inside the subpath / connection kernels (best when the
  * tree is LDS-resident), 2 = persistent traversal launches with lane-level ray replacement + one
- * bounce launch per level (best for large trees: rays of very different cost), 0 = choose by scene
- * size (default).  Results are identical for every setting. */
+ * bounce launch per level (rays of very different cost: large trees), 3 = subpaths as in 1, connection
+ * rays as in 2 (mid-size trees in serial order: no per-level launch tails), 0 (default) = 1 for
+ * LDS-resident trees, otherwise 2.  Results are identical for every setting. */
 int cl2_set_traversal_mode(cl2_renderer* r, int mode);
 /* Sample pipeline of cl2_run_samples.  The seed buffer is the only state one sample hands to the next
  * (src/renderer.py:86-87) and only the subpath stage (K1, K2, K3) touches it, so later stages of

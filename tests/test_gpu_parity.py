@@ -397,7 +397,7 @@ def test_movie_cli_writes_turntable_frames(tmp_path):
     assert not np.array_equal(frames[0], frames[1])        # the camera moved
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_sample_pipeline_is_a_pure_performance_knob(mode, glass_scene, oracle_mod):
     """run_samples as a pipeline over samples (later stages of sample i on their own streams beside
     the subpath stage of the next samples; 2 and 3 stages) == serial order == oracle: seeds, last
@@ -428,7 +428,7 @@ def test_sample_pipeline_is_a_pure_performance_knob(mode, glass_scene, oracle_mo
     r1.set_pipelining(-1)                      # by frame size (the default)
 
 
-@pytest.mark.parametrize("mode,levels,stages", [(1, 6, 0), (1, 2, 1), (2, 1, 2), (1, 0, 2)])
+@pytest.mark.parametrize("mode,levels,stages", [(1, 6, 0), (1, 2, 1), (2, 1, 2), (1, 0, 2), (3, 3, 1)])
 def test_open_scene_paths_of_every_length(mode, levels, stages, oracle_mod):
     """An OPEN scene (floor, back wall, emitter and a glass ball; no other walls): most subpaths leave
     the scene after one to three bounces, so every subpath length occurs, queues shrink from level to

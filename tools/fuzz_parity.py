@@ -59,7 +59,7 @@ def main():
         B = scene.pixel_width * scene.pixel_height
         seeds = make_seeds(B, seed=k)
         r, o = Renderer(scene, seeds=seeds), orc.OracleRenderer(scene, seeds=seeds)
-        mode, levels, stages = int(rng.randint(0, 3)), int(rng.randint(0, 7)), int(rng.randint(-1, 3))
+        mode, levels, stages = int(rng.randint(0, 4)), int(rng.randint(0, 7)), int(rng.randint(-1, 3))
         r.set_traversal_mode(mode)
         r.set_levels_per_launch(levels)
         r.set_pipelining(stages)
