@@ -2,13 +2,18 @@
 instead of opening a cv2 window (display code is out of scope).
 
     python -m clive2_amd.render --scene empty --width 1280 --height 720 --samples 64 --out cornell.png
+
+Several GPUs: `python -m torch.distributed.run --nproc-per-node N -m clive2_amd.render ...` -- every
+rank renders its share of the samples of the same frame with its own seeds, ONE sum all-reduce of the
+accumulators (RCCL) follows, rank 0 writes the picture.
 """
 import argparse
 import time
 
 import numpy as np
 
-from .renderer import Renderer, RendererError
+from .distributed import rank_info, samples_for_rank
+from .renderer import Renderer, RendererError, make_seeds
 from .scene import create_scene_from_preset
 
 
@@ -23,17 +28,29 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=0)
     args = ap.parse_args(argv)
 
+    rank, local_rank, world = rank_info()
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     scene = create_scene_from_preset(args.scene, pixel_width=args.width, pixel_height=args.height)
-    renderer = Renderer(scene, device=args.device)
+    device = local_rank if world > 1 else args.device
+    renderer = Renderer(scene, seeds=make_seeds(args.width * args.height, rank=rank), device=device)
     t0 = time.time()
     try:
-        renderer.run_samples(args.samples)
+        renderer.run_samples(samples_for_rank(args.samples, rank, world))
     except (KeyboardInterrupt, RendererError):
         if not args.save_on_quit:
             raise
+    renderer.reduce_accumulators()
     dt = time.time() - t0
     rays = renderer.counters()["rays"]
-    print(f"Rendering took {dt:.2f} seconds ({renderer.samples} samples, {rays / max(dt, 1e-9) / 1e6:.0f} Mrays/s)")
+    print(f"[rank {rank}] rendering took {dt:.2f} seconds ({renderer.samples} samples, {rays / max(dt, 1e-9) / 1e6:.0f} Mrays/s)")
+    if world > 1:
+        dist.destroy_process_group()
+    if rank != 0:
+        return 0
     image = renderer.image                      # tone-mapped uint8, BGR, row 0 = bottom of the film
     try:
         from PIL import Image
