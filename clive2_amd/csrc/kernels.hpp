@@ -569,6 +569,7 @@ constexpr int AGG_ROWS = 13;
 
 }  // namespace cl2
 #include "connect_resolve.hpp"
+#include "connect_resolve_wide.hpp"
 namespace cl2 {
 
 // ---------------------------------------------------------------- K6: adaptive_finalize_samples

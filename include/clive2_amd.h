@@ -145,8 +145,8 @@ int cl2_set_counting(cl2_renderer* r, int on);      /* node / triangle test tall
 int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
 /* performance-experiment switches.  Bits 0-2 make the result an INVALID render: bit 0 skips the t=1
  * light-image splat atomics, bit 1 / bit 2 skip the t >= 2 / t == 1 strategy pairs in the resolve kernel.
- * The others only change the launch organisation (same results): bits 4-6 register budget variant of
- * the resolve kernel; bits 8-10 eighths of the wave slots given to the subpath stage while the sample
+ * The others only change the launch organisation (same results): bits 4-6 variant of the resolve
+ * kernel (2 / 4: register budget; 7: one wave per camera vertex); bits 8-10 eighths of the wave slots given to the subpath stage while the sample
  * pipeline runs on a large scene (0 = tuned); bit 12 inverts the one/two-triangles-per-step choice of
  * the persistent walk. */
 int cl2_set_debug_flags(cl2_renderer* r, int flags);

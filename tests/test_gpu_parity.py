@@ -462,3 +462,26 @@ def test_open_scene_paths_of_every_length(mode, levels, stages, oracle_mod):
     np.testing.assert_allclose(img, o.summed_image, rtol=5e-5, atol=1e-8)
     np.testing.assert_allclose(wts, o.summed_sample_weights, rtol=5e-5, atol=1e-8)
     assert r.counters()["rays"] == o.rays_traced
+
+
+@pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
+def test_wide_resolve_kernel_agrees(scene_name, request, oracle_mod):
+    """The second implementation of the resolve stage (one wave per camera vertex, running total relayed
+    between the waves; csrc/connect_resolve_wide.hpp) reproduces the oracle's aggregators, unidirectional
+    estimate and image exactly like the default one-thread-per-pixel kernel."""
+    scene = request.getfixturevalue(scene_name)
+    r, o = _pair(scene, oracle_mod)
+    r.set_debug_flags(7 << 4)
+    _run_to_paths(r, o)
+    _run_rest(r, o)
+    agg = r.export_aggregators()
+    assert agg["total_contribution"].tobytes() == o.weight_aggregators["total_contribution"].tobytes()
+    assert agg["weights"].tobytes() == o.weight_aggregators["weights"].tobytes()
+    assert agg["contrib_weight_sum"].tobytes() == o.weight_aggregators["contrib_weight_sum"].tobytes()
+    r.run_samples(3)
+    for _ in range(3):
+        o.run_sample()
+    img, wts, cnt, uni = r.read_accumulators()
+    np.testing.assert_allclose(uni, o.unidirectional_image_buffer, rtol=1e-6, atol=0)
+    np.testing.assert_allclose(img, o.summed_image, rtol=5e-5, atol=1e-8)
+    np.testing.assert_allclose(wts, o.summed_sample_weights, rtol=5e-5, atol=1e-8)
