@@ -485,3 +485,50 @@ def test_wide_resolve_kernel_agrees(scene_name, request, oracle_mod):
     np.testing.assert_allclose(uni, o.unidirectional_image_buffer, rtol=1e-6, atol=0)
     np.testing.assert_allclose(img, o.summed_image, rtol=5e-5, atol=1e-8)
     np.testing.assert_allclose(wts, o.summed_sample_weights, rtol=5e-5, atol=1e-8)
+
+
+def test_c_abi_error_behaviour(cornell_small):
+    """The boundary's error contract (include/clive2_amd.h): every entry point returns a negative code,
+    leaves a message for cl2_last_error, never crashes, and the handle stays usable afterwards."""
+    import ctypes as C
+    from clive2_amd import _native
+    from clive2_amd.renderer import Renderer, make_seeds
+    L = _native.lib()
+    B = cornell_small.pixel_width * cornell_small.pixel_height
+    # creation: bad frame sizes, bad device
+    h = C.c_void_p()
+    assert L.cl2_create(0, 0, 16, C.byref(h)) < 0 and not h.value
+    assert L.cl2_create(0, 1 << 14, 1 << 13, C.byref(h)) < 0 and not h.value           # >= 2^26 pixels
+    assert L.cl2_create(9999, 16, 16, C.byref(h)) < 0 and not h.value
+    assert b"device" in L.cl2_last_error(None) or b"range" in L.cl2_last_error(None)
+    # a fresh handle without a scene refuses to render
+    assert L.cl2_create(0, 16, 16, C.byref(h)) == 0 and h.value
+    assert L.cl2_run_samples(h, 1) < 0 and b"scene" in L.cl2_last_error(h)
+    assert L.cl2_make_light_rays(h) < 0
+    L.cl2_destroy(h)
+    # NULL handles
+    assert L.cl2_run_samples(None, 1) < 0 and L.cl2_set_pipelining(None, 1) < 0
+    L.cl2_destroy(None)                                                                # no-op
+
+    r = Renderer(cornell_small, seeds=make_seeds(B))
+    hh = r._h
+    # wrong sizes / ranges
+    buf = np.zeros(8 * B + 1, dtype=np.float32)
+    assert L.cl2_read_accumulators_packed(hh, buf.ctypes.data_as(C.c_void_p), C.c_size_t(8 * B + 1)) < 0
+    assert L.cl2_set_seeds(hh, buf.ctypes.data_as(C.c_void_p), C.c_size_t(3)) < 0
+    assert L.cl2_run_samples(hh, -1) < 0
+    assert L.cl2_set_traversal_mode(hh, 9) < 0 and L.cl2_set_pipelining(hh, 5) < 0 and L.cl2_set_levels_per_launch(hh, -2) < 0
+    assert L.cl2_export_paths(hh, 0, buf.ctypes.data_as(C.c_void_p), C.c_size_t(B + 1)) < 0
+    # a scene that fails validation is rejected and the old one stays in place
+    boxes = np.array(cornell_small.boxes, copy=True)
+    boxes["left"][0] = 9999                                                            # child index out of range
+    import copy
+    bad = copy.copy(cornell_small)
+    bad.boxes = boxes
+    bad.validate = lambda: None                # skip the host-side check: the library must catch it
+    with pytest.raises(_native.RendererError):
+        r.upload_scene(bad)
+    # ... and the renderer still works
+    r.upload_scene(cornell_small)
+    r.run_samples(2)
+    assert np.isfinite(r.packed_accumulators()).all() and r.counters()["rays"] > 0
