@@ -39,21 +39,28 @@ struct BvhView {
     int lds_tris;            // 1: all triangles staged in LDS (n_tris <= LDS_TRI_CAP)
 };
 
-constexpr int LDS_NODE_CAP = 256;   // 256 * 32 B = 8 KB
-constexpr int LDS_TRI_CAP = 128;    // 128 * 48 B = 6 KB
+constexpr int LDS_NODE_CAP = 512;   // records in the LDS window: at most 512 * 32 B = 16 KB
+constexpr int LDS_TRI_CAP = 512;    // triangles staged in LDS when the whole scene has no more: at most 512 * 48 B = 24 KB
 constexpr int LEAF_PACK_MAX = 16;   // triangles per leaf record
 
+// The staged part of the tree lives in DYNAMIC shared memory sized by the scene (bvh_lds_bytes on the
+// host): the Cornell box takes 1 KB, a 500-triangle scene 40 KB -- one kernel serves both without the
+// small scene paying for the large one's reservation.
 struct BvhLds {
-    float4 nodes[2 * LDS_NODE_CAP];
-    float4 tris[3 * LDS_TRI_CAP];
+    const float4* nodes;     // 2 float4 per staged record
+    const float4* tris;      // 3 float4 per triangle (only when b.lds_tris)
 };
 
 // Cooperative copy of the staged part of the tree; every thread of the block must call it.
 __device__ __forceinline__ void stage_bvh(BvhLds& s, const BvhView& b) {
+    extern __shared__ float4 cl2_tree_lds[];
+    float4* nodes = cl2_tree_lds;
+    float4* tris = cl2_tree_lds + 2 * b.n_lds_nodes;
     const int nt = blockDim.x, t = threadIdx.x;
-    for (int i = t; i < 2 * b.n_lds_nodes; i += nt) s.nodes[i] = b.nodes[i];
+    for (int i = t; i < 2 * b.n_lds_nodes; i += nt) nodes[i] = b.nodes[i];
     if (b.lds_tris)
-        for (int i = t; i < 3 * b.n_tris; i += nt) s.tris[i] = b.tris[i];
+        for (int i = t; i < 3 * b.n_tris; i += nt) tris[i] = b.tris[i];
+    s.nodes = nodes; s.tris = tris;
     __syncthreads();
 }
 

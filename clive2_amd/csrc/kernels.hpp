@@ -42,6 +42,7 @@ constexpr int WAVES_PER_BLOCK = BLOCK / 64;
 constexpr int MAX_VERTS = 6;          // bounce loop bound, trace.metal:407
 constexpr int CONN_SLOTS = 36;        // (t in 1..6) x (s in 1..6) strategy pairs that need a ray
 constexpr int TAG_PID_BITS = 26;
+constexpr int SHADE_LDS_CAP = 128;   // shading triangles staged in LDS by the subpath kernel (64 B each)
 constexpr int LDS_MAT_CAP = 32;      // materials staged in LDS by the subpath kernel
 constexpr int META_HIT_LIGHT = 1 << 8;
 constexpr int META_HIT_CAMERA = 1 << 9;
@@ -162,7 +163,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_traverse_paths(
         BvhView bvh, const int* __restrict__ queue, const unsigned* __restrict__ count,
         const float4* __restrict__ P0v, const float4* __restrict__ P1v, float4* __restrict__ hit, Stats* stats) {
-    __shared__ BvhLds lds;
+    BvhLds lds{nullptr, nullptr};
     stage_bvh(lds, bvh);
     const unsigned n = *count;
     const unsigned j = blockIdx.x * BLOCK + threadIdx.x;
@@ -218,7 +219,7 @@ template <bool COUNT, bool TWO_TRIS, class Source>
 __global__ __launch_bounds__(BLOCK) void k_traverse_persistent(BvhView bvh, const unsigned* __restrict__ count,
                                                               unsigned* __restrict__ work_counter, Source src, Stats* stats,
                                                               int is_conn) {
-    __shared__ BvhLds lds;
+    BvhLds lds{nullptr, nullptr};
     stage_bvh(lds, bvh);
     const unsigned n = *count;
     unsigned nb = 0, nt = 0;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_persistent(BvhView bvh, cons
 // Vertices `first` (written by the generator or the previous launch) is patched in place; the vertex
 // created at level end-1 is written complete (reverse pdf still open) when the path goes on.
 struct ShadeLds {
-    float4 tri_shade[4 * LDS_TRI_CAP];
+    float4 tri_shade[4 * SHADE_LDS_CAP];
     MaterialDev mats[LDS_MAT_CAP];
 };
 
@@ -264,9 +265,9 @@ __global__ __launch_bounds__(BLOCK, 6) void k_trace_subpath(
         const float4* __restrict__ ext_hit) {
     // EXT_HIT: the closest hits of the (single) level were produced by k_traverse_persistent (large
     // scenes: traversal with ray replacement runs as its own launch); the BVH is not staged here.
-    __shared__ BvhLds lds;
+    BvhLds lds{nullptr, nullptr};
     __shared__ ShadeLds sh;
-    const bool shade_lds = bvh.lds_tris != 0, mats_lds = n_mats <= LDS_MAT_CAP;
+    const bool shade_lds = bvh.n_tris <= SHADE_LDS_CAP, mats_lds = n_mats <= LDS_MAT_CAP;
     if (shade_lds) for (int i = threadIdx.x; i < 4 * bvh.n_tris; i += BLOCK) sh.tri_shade[i] = tri_shade_g[i];
     if (mats_lds) for (int i = threadIdx.x; i < n_mats; i += BLOCK) sh.mats[i] = mats_g[i];
     if (!EXT_HIT) stage_bvh(lds, bvh);                     // ends with the barrier
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_conn(
         BvhView bvh, int B, const unsigned* __restrict__ count, const int* __restrict__ ctag,
         const float4* __restrict__ LP0, const float4* __restrict__ CP0, CameraRec cam,
         float2* __restrict__ chit, Stats* stats) {
-    __shared__ BvhLds lds;
+    BvhLds lds{nullptr, nullptr};
     stage_bvh(lds, bvh);
     const unsigned n = *count;
     const V3 focal = cam3(cam.focal_point);

@@ -182,6 +182,10 @@ int launch_generate(cl2_renderer* r, int which, hipStream_t st, const PathBufs* 
 // In serial order fused wins on mid-size trees (5k-triangle sphere: 5.7 vs 8.7 ms per sample), but
 // the sample pipeline with stage shares hides the tails of the persistent form and then the two are
 // equal there (6.05 vs 6.00 Grays/s) and persistent wins from 82k triangles on (4.7 vs 3.9).
+// dynamic shared memory of a launch that stages the tree (stage_bvh)
+inline size_t bvh_lds_bytes(const cl2_renderer* r) {
+    return ((size_t)2 * r->bvh.n_lds_nodes + (r->bvh.lds_tris ? (size_t)3 * r->bvh.n_tris : 0)) * sizeof(float4);
+}
 inline bool tree_in_lds(const cl2_renderer* r) { return r->bvh.lds_tris && r->bvh.n_nodes <= r->bvh.n_lds_nodes; }
 inline bool split_paths(const cl2_renderer* r) {
     if (r->traversal_mode == 1 || r->traversal_mode == 3) return false;
@@ -252,7 +256,7 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
             Timed t(r, ST_TRAVERSE_PATHS, st);
             PathRaySource src{q_in, pb.P0 + (size_t)first * B, pb.P1 + (size_t)first * B, r->d_hit};
 #define CL2_PERSIST(CNT, TWO)                                                                                              \
-            hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, PathRaySource>), dim3(persistent_grid_paths(r)), dim3(BLOCK), 0, \
+            hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, PathRaySource>), dim3(persistent_grid_paths(r)), dim3(BLOCK), bvh_lds_bytes(r), \
                                st, r->bvh, c_in, r->d_work + first, src, r->d_stats, 0)
             if (two_tris_per_step(r)) { if (r->counting) CL2_PERSIST(true, true); else CL2_PERSIST(false, true); }
             else { if (r->counting) CL2_PERSIST(true, false); else CL2_PERSIST(false, false); }
@@ -262,7 +266,7 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
         }
         Timed t(r, split ? ST_BOUNCE : ST_TRAVERSE_PATHS, st);
 #define CL2_TRACE(CAM, CNT, EXT)                                                                                          \
-        hipLaunchKernelGGL((k_trace_subpath<CAM, CNT, EXT>), dim3(grid_for(B)), dim3(BLOCK), 0, st, r->bvh, r->d_stats,          \
+        hipLaunchKernelGGL((k_trace_subpath<CAM, CNT, EXT>), dim3(grid_for(B)), dim3(BLOCK), (EXT) ? 0 : bvh_lds_bytes(r), st, r->bvh, r->d_stats, \
                            first, end, q_in, c_in, q_out, c_out, B, pb, r->d_seeds, r->d_tri_shade, r->d_mats, r->n_mats,        \
                            r->d_block_stats, r->d_hit)
         if (split) { if (which == CL2_CAMERA) CL2_TRACE(true, false, true); else CL2_TRACE(false, false, true); }
@@ -294,7 +298,7 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
             ConnRaySource src{r->d_ctag, lp.P0, cp.P0, r->d_chit[cs],
                               V3{r->cam.focal_point[0], r->cam.focal_point[1], r->cam.focal_point[2]}, B};
 #define CL2_PERSIST(CNT, TWO)                                                                                             \
-            hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, ConnRaySource>), dim3(persistent_grid_conn(r)), dim3(BLOCK), 0, \
+            hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, ConnRaySource>), dim3(persistent_grid_conn(r)), dim3(BLOCK), bvh_lds_bytes(r), \
                                st, r->bvh, r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1)
             if (two_tris_per_step(r)) { if (r->counting) CL2_PERSIST(true, true); else CL2_PERSIST(false, true); }
             else { if (r->counting) CL2_PERSIST(true, false); else CL2_PERSIST(false, false); }
@@ -303,10 +307,10 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
             // grid-stride over the (device-side) ray count; enough workgroups to fill 256 CUs several times over
             const int grid = std::min<size_t>(grid_for((size_t)B * 8), 256 * 32);
             if (r->counting)
-                hipLaunchKernelGGL(k_traverse_conn<true>, dim3(grid), dim3(BLOCK), 0, st, r->bvh, B, r->d_qcount + 7, r->d_ctag,
+                hipLaunchKernelGGL(k_traverse_conn<true>, dim3(grid), dim3(BLOCK), bvh_lds_bytes(r), st, r->bvh, B, r->d_qcount + 7, r->d_ctag,
                                    lp.P0, cp.P0, r->cam, r->d_chit[cs], r->d_stats);
             else
-                hipLaunchKernelGGL(k_traverse_conn<false>, dim3(grid), dim3(BLOCK), 0, st, r->bvh, B, r->d_qcount + 7, r->d_ctag,
+                hipLaunchKernelGGL(k_traverse_conn<false>, dim3(grid), dim3(BLOCK), bvh_lds_bytes(r), st, r->bvh, B, r->d_qcount + 7, r->d_ctag,
                                    lp.P0, cp.P0, r->cam, r->d_chit[cs], r->d_stats);
         }
         r->launches_tc++;
@@ -1045,9 +1049,9 @@ int cl2_probe_traverse(cl2_renderer* r, const void* rays_v, size_t n_rays, int32
     }
     if (rc == CL2_OK) {
         if (r->counting)
-            hipLaunchKernelGGL(k_traverse_paths<true>, dim3(grid_for(n_rays)), dim3(BLOCK), 0, r->stream, r->bvh, (const int*)nullptr, d_n, d_o, d_d, d_h, r->d_stats);
+            hipLaunchKernelGGL(k_traverse_paths<true>, dim3(grid_for(n_rays)), dim3(BLOCK), bvh_lds_bytes(r), r->stream, r->bvh, (const int*)nullptr, d_n, d_o, d_d, d_h, r->d_stats);
         else
-            hipLaunchKernelGGL(k_traverse_paths<false>, dim3(grid_for(n_rays)), dim3(BLOCK), 0, r->stream, r->bvh, (const int*)nullptr, d_n, d_o, d_d, d_h, r->d_stats);
+            hipLaunchKernelGGL(k_traverse_paths<false>, dim3(grid_for(n_rays)), dim3(BLOCK), bvh_lds_bytes(r), r->stream, r->bvh, (const int*)nullptr, d_n, d_o, d_d, d_h, r->d_stats);
         rc = drain(r);
     }
     if (rc == CL2_OK && hipMemcpy(h.data(), d_h, n_rays * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(r, CL2_E_HIP, "probe download failed");
