@@ -66,6 +66,19 @@ def measured_traffic(kernel):
     return None, None
 
 
+def measured_valu(kernel):
+    """VALU wave-instructions per launch of `kernel` from the committed rocprofv3 SQ pass
+    (profiles/r01_final_pmc_sq.txt, SQ_INSTS_VALU); None when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_final_pmc_sq.txt")
+    try:
+        for line in open(path):
+            if line.startswith(kernel + "<false>") and "INSTS_VALU=" in line:
+                return float(line.split("INSTS_VALU=")[1].split()[0])
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
 def build_scene(name, W, H):
     import numpy as np
     import clive2_amd as c2
@@ -213,6 +226,18 @@ def main():
             else "k_traverse_persistent<ConnRaySource>"
         achieved = (k_rays * b_ray) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_src = measured_traffic(k_name) if args.scene == "cornell" and (W, H) == (1920, 1080) else (None, None)
+        # what actually bounds the kernel on this scene (the tree is LDS-resident): VALU issue.  Wave-instructions
+        # per launch from the committed SQ counters x the measured issue cost (tools/valu_rate.hip: 2.3 cycles
+        # per fp32 wave-instruction; divides dearer, so this is a floor) over 1024 SIMDs at the 2.4 GHz clock,
+        # against the duration of the launch running alone
+        valu = None
+        n_valu = measured_valu(k_name) if args.scene == "cornell" and (W, H) == (1920, 1080) else None
+        if n_valu and cb["ms_traverse_conn"] > 0:
+            issue_ms = n_valu * 2.3 / (1024 * 2.4e9) * 1e3
+            alone_ms = cb["ms_traverse_conn"] / max(cb["launches_traverse_conn"], 1)
+            valu = {"kernel": k_name, "wave_insts_per_launch": n_valu, "issue_floor_ms": round(issue_ms, 4),
+                    "launch_alone_ms": round(alone_ms, 4), "frac": round(issue_ms / alone_ms, 4),
+                    "source": "profiles/r01_final_pmc_sq.txt (SQ_INSTS_VALU) x 2.3 cycles (tools/valu_rate.hip)"}
         out = {
             "metric": "Mrays/sec (whole node) + HBM GB/s, 1080p Cornell box, 1/2/4/8 MI355X",
             "value": round(rays_total / dt / 1e6, 2),
@@ -237,6 +262,7 @@ def main():
                          "frac_serial": round((cb["rays_traverse_conn"] * b_ray) / max(cb["ms_traverse_conn"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
                          "sample_pipeline_stages": args.pipelining},
             "stage_ms_per_step_serial": stages,
+            "valu": valu,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_width, args.cpu_height, args.cpu_samples)
