@@ -145,6 +145,8 @@ def main():
     backend = os.environ.get("CLIVE2_BENCH_BACKEND", "nccl")
     if os.environ.get("CLIVE2_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+    # a launcher may expose one GPU per rank (HIP_VISIBLE_DEVICES=<rank>): then the rank's GPU is device 0
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -32,6 +32,7 @@ def main(argv=None):
     if world > 1:
         import torch
         import torch.distributed as dist
+        local_rank %= max(torch.cuda.device_count(), 1)       # one visible GPU per rank: it is device 0
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     scene = create_scene_from_preset(args.scene, pixel_width=args.width, pixel_height=args.height)
