@@ -15,7 +15,7 @@ import time
 import numpy as np
 
 from .distributed import rank_info
-from .renderer import Renderer
+from .renderer import Renderer, RendererError
 from .scene import create_scene_from_preset_with_params
 
 
@@ -53,7 +53,12 @@ def main(argv=None):
         t0 = time.time()
         scene = create_scene_from_preset_with_params(args.scene, pixel_width=args.width, pixel_height=args.height,
                                                      frame_idx=f, total_frames=args.movie_frames)
-        renderer = Renderer(scene, device=local_rank)
+        try:
+            renderer = Renderer(scene, device=local_rank)
+        except RendererError:
+            if local_rank == 0:
+                raise
+            renderer = Renderer(scene, device=0)     # the launcher exposes one GPU per rank: it is device 0
         renderer.run_samples(args.samples)
         save_frame(os.path.join(out_dir, f"frame_{f:04d}.png"), renderer.image)
         del renderer, scene
