@@ -284,7 +284,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
         float2 hits[MAX_VERTS + 1];
         hits[0] = make_float2(0.0f, 0.0f);
 #pragma unroll
-        for (int s = 1; s <= MAX_VERTS; s++) hits[s] = chit[(size_t)conn_slot(t, s) * B + pid];
+        for (int s = 1; s <= MAX_VERTS; s++) hits[s] = chit_load(chit, B, t, s, pid);
         if ((debug_flags & 2) && t >= 2) continue;      // experiment switches: skip the t >= 2 / t == 1 pairs
         if ((debug_flags & 4) && t == 1) continue;
 #define CL2_PAIR(S)                                                                                             \

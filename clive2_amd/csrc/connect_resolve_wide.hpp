@@ -268,7 +268,7 @@ __global__ __launch_bounds__(RW_BLOCK) void k_connect_resolve_wide(
     float2 hits[MAX_VERTS + 1];
     hits[0] = make_float2(0.0f, 0.0f);
 #pragma unroll
-    for (int s = 1; s <= MAX_VERTS; s++) hits[s] = have_t ? chit[(size_t)conn_slot(t, s) * B + pid] : make_float2(0.0f, 0.0f);
+    for (int s = 1; s <= MAX_VERTS; s++) hits[s] = have_t ? chit_load(chit, B, t, s, pid) : make_float2(0.0f, 0.0f);
     const unsigned long long mask = valid ? cmask[pid] : 0ull;
     __syncthreads();
 

@@ -197,6 +197,20 @@ struct PathRaySource {          // subpath rays: queue entry -> pixel -> (P0.xyz
     }
 };
 
+// Closest-hit results of the connection rays: the hit triangle for every slot (all the t >= 2 pairs need,
+// visibility_test compares triangles only) and the distance for the six t = 1 slots (the film projection,
+// world_ray_to_camera_ray, needs it).  One allocation: int tri[36][B] followed by float t1[6][B].
+__device__ __forceinline__ void chit_store(float2* chit, int B, int slot, int pid, int tri, float t) {
+    reinterpret_cast<int*>(chit)[(size_t)slot * B + pid] = tri;
+    if (slot < MAX_VERTS) (reinterpret_cast<float*>(chit) + (size_t)CONN_SLOTS * B)[(size_t)slot * B + pid] = t;
+}
+__device__ __forceinline__ float2 chit_load(const float2* chit, int B, int t, int s, int pid) {
+    const int slot = (t - 1) * 6 + (s - 1);
+    const int tri = reinterpret_cast<const int*>(chit)[(size_t)slot * B + pid];
+    const float dist = (t == 1) ? (reinterpret_cast<const float*>(chit) + (size_t)CONN_SLOTS * B)[(size_t)slot * B + pid] : 0.0f;
+    return make_float2(__int_as_float(tri), dist);
+}
+
 struct ConnRaySource {          // connection rays: tag {slot, pixel} -> light vertex s-1 toward focal point / camera vertex t-1
     const int* ctag; const float4* LP0; const float4* CP0; float2* chit; V3 focal; int B;
     __device__ __forceinline__ void load(unsigned j, V3& o, V3& d) const {
@@ -211,7 +225,7 @@ struct ConnRaySource {          // connection rays: tag {slot, pixel} -> light v
     __device__ __forceinline__ void store(unsigned j, const Hit& h) const {
         const int tag = ctag[j];
         const int pid = tag & ((1 << TAG_PID_BITS) - 1), slot = (unsigned)tag >> TAG_PID_BITS;
-        chit[(size_t)slot * B + pid] = make_float2(__int_as_float(h.tri), h.t);
+        chit_store(chit, B, slot, pid, h.tri, h.t);
     }
 };
 
@@ -549,7 +563,7 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_conn(
         if (t > 1) target = v3(CP0[(size_t)(t - 1) * B + pid]);
         const V3 d = normalize(target - o);
         const Hit h = closest_hit<COUNT>(lds, bvh, o, d, rcp3(d), nb, nt);
-        chit[(size_t)slot * B + pid] = make_float2(__int_as_float(h.tri), h.t);
+        chit_store(chit, B, slot, pid, h.tri, h.t);
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) { nb += __shfl_down(nb, off); nt += __shfl_down(nt, off); }
