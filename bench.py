@@ -4,20 +4,32 @@
 One "step" = one sample of the full BDPT pipeline (Renderer.run_sample: light + camera subpaths,
 all (t,s) connections, light splat, filter, accumulate) over the whole 1920x1080 frame on every
 rank.  Ranks are weak-scaled (each integrates its own samples of the replicated scene, own seed
-buffer); the accumulators are summed once with an RCCL all-reduce inside the timed region.
-One "ray" = one closest-hit BVH query; rays are counted on the device.
+buffer); the accumulators are summed once with an in-place RCCL all-reduce (inside the library,
+cl2_reduce_accumulators) inside the timed region.  One "ray" = one closest-hit BVH query
+(SURVEY.md §8d); rays are counted on the device.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--width 1920 --height 1080]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant traversal kernel with the
-algorithmic bytes of SURVEY.md §8(d): B_ray = 48 + 32*N_node + 36*N_tri, N_node/N_tri measured by
-device counters in a separate (untimed) counting pass, kernel time from HIP events recorded on
-the renderer's stream during the timed region.  `cpu_baseline` times the C oracle (the CPU
-restatement of the reference's kernels, OpenMP over host cores) on a bounded sample.
+Only RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are read from the launcher's environment: torch is
+not imported (the library runs on the ROCm runtime it was built for; barrier, max-over-ranks clock
+and ray tally go through cl2_comm_allreduce_f64).  Rank 0 prints ONE JSON line.
+
+`roofline` describes the dominant kernel (the connection-ray traversal launch, 70 % of all rays):
+its duration is measured live with HIP events on the stream it is launched on.  On the Cornell box
+the whole tree lives in LDS, so the bound is VALU issue (wave-instructions x 2 cycles, SIMD-32
+wave64, MI355X_MICROARCH.md) -- the algorithmic-bytes formula of SURVEY.md §8(d),
+B_ray = 48 + 32*N_node + 36*N_tri, is reported beside it but prices bytes that never leave LDS.
+Instruction counts and HBM bytes per launch come from committed rocprofv3 PMC passes and are
+marked "static" (used only while the kernel sources still hash to what was profiled).
+`roofline_mesh` is the same launch on the config-3 mesh scene (tree in L2, not LDS), where the
+formula is a memory statement.  `cpu_baseline` times the C oracle (CPU restatement of the
+reference's kernels, OpenMP over host cores) on a bounded sample.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -25,8 +37,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL across processes needs dmabuf IPC on this pool
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# VALU issue peak: 256 CUs x 4 SIMD-32, a wave64 instruction occupies its SIMD for 2 cycles at 2.4 GHz
+VALU_PEAK_GINST = 1024 * 2.4e9 / 2.0 / 1e9
 
 
 def cpu_baseline(width, height, samples):
@@ -35,7 +50,6 @@ def cpu_baseline(width, height, samples):
     # a GPU box exposes all host threads but grants a 16-CPU share: size the OpenMP team to it
     os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-    import numpy as np
     import clive2_amd as c2
     from oracle import oracle as orc
     orc.build()
@@ -51,32 +65,32 @@ def cpu_baseline(width, height, samples):
                       f"({o.rays_traced} rays, {dt:.1f} s; C oracle, OpenMP)"}
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note of
-    MI355X_MICROARCH.md); None when no summary is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_final_pmc_hbm.json")
-    try:
-        table = json.load(open(path))["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None, None
-    for name, val in table.items():
-        if kernel in name and "true" not in name.split("<")[-1]:
-            return val, "profiles/r01_final_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 1080p Cornell)"
-    return None, None
+def kernel_sources_sha():
+    """Hash of everything that is compiled into the library: a committed PMC summary is only quoted
+    while the kernels it profiled are the kernels that run."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "clive2_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
-def measured_valu(kernel):
-    """VALU wave-instructions per launch of `kernel` from the committed rocprofv3 SQ pass
-    (profiles/r01_final_pmc_sq.txt, SQ_INSTS_VALU); None when no summary is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_final_pmc_sq.txt")
+def static_pmc(scene, W, H):
+    """Per-launch PMC figures of the connection-ray traversal kernel from profiles/r02_pmc_<scene>.json
+    (tools/profile_round.sh + tools/profile_summaries.py: rocprofv3 --pmc passes of this same command), or
+    None when there is no summary for this scene / frame size, or the kernel sources have changed since
+    it was taken."""
+    path = os.path.join(ROOT, "profiles", f"r02_pmc_{scene}.json")
     try:
-        for line in open(path):
-            if line.startswith(kernel + "<false>") and "INSTS_VALU=" in line:
-                return float(line.split("INSTS_VALU=")[1].split()[0])
-    except (OSError, ValueError, IndexError):
-        pass
-    return None
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if d.get("sources_sha") != kernel_sources_sha() or (d.get("width"), d.get("height")) != (W, H):
+        return None
+    row = d.get("kernels", {}).get(d.get("conn_traversal_kernel"))
+    if not row:
+        return None
+    return dict(row, source=f"profiles/r02_pmc_{scene}.json", sources_sha=d["sources_sha"])
 
 
 def build_scene(name, W, H):
@@ -107,6 +121,120 @@ def build_scene(name, W, H):
     return s, desc + f", {len(s.triangles)} tris / {len(s.boxes)} boxes"
 
 
+def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world, with_comm):
+    """Warm-up (+ counting pass), the timed region, a serial per-stage breakdown.  Returns the pieces
+    of the JSON line that depend on the workload."""
+    import clive2_amd as c2  # noqa: F401
+    from clive2_amd import _native
+    from clive2_amd.renderer import Renderer, make_seeds
+    from clive2_amd.distributed import join_communicator
+
+    scene, scene_desc = build_scene(scene_name, W, H)
+    n_dev = max(_native.lib().cl2_device_count(), 1)
+    # a launcher may expose one GPU per rank (HIP_VISIBLE_DEVICES=<rank>): then the rank's GPU is device 0
+    r = Renderer(scene, seeds=make_seeds(W * H, rank=rank), device=local_rank % n_dev)
+    if with_comm:
+        join_communicator(r, rank, world)        # untimed: communicator and its buffers exist before the clock starts
+
+    def barrier():
+        r.synchronize()
+        if with_comm:
+            r.allreduce_host([0.0], op="max")
+        r.synchronize()
+
+    r.set_levels_per_launch(args.levels_per_launch)
+    r.set_traversal_mode(args.traversal_mode)
+    r.set_pipelining(args.pipelining)
+
+    # untimed: warm-up (also the counting pass that measures N_node / N_tri per ray)
+    r.set_counting(True)
+    r.run_samples(max(warmup, 1))
+    cw = r.counters()
+    n_node = cw["box_tests"] / max(cw["counted_rays"], 1)
+    n_tri = cw["tri_tests"] / max(cw["counted_rays"], 1)
+    r.set_counting(False)
+    if with_comm:
+        r.reduce_accumulators()      # untimed: first use of the collective (channel set-up) before the clock starts
+    r.reset_counters()
+    r.reset_accumulators()
+    r.set_profiling(1)               # timed region: HIP events around the connection-ray traversal launch only
+    if args.debug_flags:
+        r.set_debug_flags(args.debug_flags)
+
+    barrier()
+    t0 = time.perf_counter()
+    r.run_samples(steps)
+    if with_comm:
+        r.reduce_accumulators()
+    barrier()
+    dt = time.perf_counter() - t0
+
+    c = r.counters()
+    rays_local = c["rays"]
+    # untimed: per-stage breakdown (HIP events around every launch) over a few more samples, in serial
+    # order on one stream -- with the sample pipeline on, spans of the two streams overlap and a
+    # stage's span includes whatever ran beside it
+    n_break = min(steps, 8)
+    r.reset_counters()
+    r.set_profiling(2)
+    r.set_pipelining(0)
+    r.run_samples(n_break)
+    cb = r.counters()
+    r.set_profiling(0)
+    r.set_pipelining(args.pipelining)
+    if with_comm:
+        rays_total = r.allreduce_host([float(rays_local)], op="sum")[0]
+        dt = r.allreduce_host([dt], op="max")[0]
+    else:
+        rays_total = float(rays_local)
+
+    out = None
+    if rank == 0:
+        import numpy as np
+        img, wts, cnt, _ = r.read_accumulators()
+        # after the reduce every rank holds the sums of all ranks (and the breakdown pass added n_break samples)
+        assert np.isfinite(img).all() and (cnt >= steps * world).all(), "accumulators corrupt"
+        # cl2_upload_scene stages the whole tree in LDS up to 512 records and 512 triangles
+        in_lds = len(scene.triangles) <= 512 and len(scene.boxes) <= 512
+        persistent = args.traversal_mode in (2, 3) or (args.traversal_mode == 0 and not in_lds)
+        k_name = "k_traverse_persistent<ConnRaySource>" if persistent else "k_traverse_conn"
+        b_ray = 48.0 + 32.0 * n_node + 36.0 * n_tri
+        k_ms, k_rays, k_launches = c["ms_traverse_conn"], c["rays_traverse_conn"], max(c["launches_traverse_conn"], 1)
+        avg_ms = k_ms / k_launches
+        alone_ms = cb["ms_traverse_conn"] / max(cb["launches_traverse_conn"], 1)
+        rays_per_launch = k_rays / k_launches
+        alg_gbs = rays_per_launch * b_ray / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        alg_gbs_alone = (cb["rays_traverse_conn"] / max(cb["launches_traverse_conn"], 1)) * b_ray / max(alone_ms * 1e-3, 1e-12) / 1e9
+        pmc = static_pmc(scene_name, W, H)
+        traffic = pmc.get("hbm_bytes") if pmc else None
+        hbm = {"algorithmic_gbs": round(alg_gbs, 1), "algorithmic_gbs_launch_alone": round(alg_gbs_alone, 1),
+               "bytes_per_ray": round(b_ray, 1), "n_node": round(n_node, 3), "n_tri": round(n_tri, 3),
+               "measured_gbs": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic and avg_ms > 0 else None,
+               "measured_frac_of_peak": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_ms > 0 else None,
+               "peak_gbs": HBM_PEAK_GBS}
+        common = {"kernel": k_name, "rays_per_launch": round(rays_per_launch), "avg_launch_ms": round(avg_ms, 4),
+                  "avg_launch_ms_alone": round(alone_ms, 4), "traffic": traffic,
+                  "static": {"what": "traffic and wave_insts_per_launch (rocprofv3 PMC passes of this command, committed)",
+                             "source": pmc["source"], "sources_sha": pmc["sources_sha"]} if pmc else None}
+        if in_lds:
+            # tree and triangles staged in LDS: the launch is bound by VALU issue, not by HBM
+            n_valu = pmc.get("SQ_INSTS_VALU") if pmc else None
+            ach = n_valu / (avg_ms * 1e-3) / 1e9 if n_valu and avg_ms > 0 else None
+            roof = {"bound": "valu", "achieved": round(ach, 1) if ach else None, "peak": round(VALU_PEAK_GINST, 1),
+                    "unit": "G wave-instructions/s", "frac": round(ach / VALU_PEAK_GINST, 4) if ach else None,
+                    "frac_launch_alone": round(n_valu / (alone_ms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4) if n_valu and alone_ms > 0 else None,
+                    "wave_insts_per_launch": n_valu, "cycles_per_wave_inst": 2.0, "hbm": hbm}
+        else:
+            roof = {"bound": "hbm", "achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(alg_gbs / HBM_PEAK_GBS, 4), "frac_launch_alone": round(alg_gbs_alone / HBM_PEAK_GBS, 4),
+                    "hbm": hbm}
+        roof.update(common)
+        out = {"scene_desc": scene_desc, "rays_total": rays_total, "rays_local": rays_local, "dt": dt, "roofline": roof,
+               "stages": {k[3:]: round(cb[k] / n_break, 4) for k in cb if k.startswith("ms_")}}
+    r.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,6 +243,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mesh", action="store_true", help="skip the second (config-3 mesh) workload of the N=1 line")
+    ap.add_argument("--mesh-steps", type=int, default=48)
     ap.add_argument("--debug-flags", type=int, default=0, help="performance experiments only (invalid renders)")
     ap.add_argument("--scene", default="cornell", choices=["cornell", "glass", "blob", "interior", "open"],
                     help="cornell = the BASELINE metric's workload (default); the others are the mesh configs "
@@ -132,147 +262,44 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+            sys.exit("bench.py --gpus N>1 must be started as one process per GPU with RANK/LOCAL_RANK/WORLD_SIZE set "
+                     "(e.g. python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...)")
         args.gpus = world
-
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
+    if not os.path.exists("/dev/kfd"):
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    # Rehearsal knobs (NOT used by the driver): CLIVE2_BENCH_BACKEND=gloo reduces through the host and
-    # CLIVE2_BENCH_SHARE_GPU=1 puts every rank on cuda:0, so the N>1 code path can be exercised on a
-    # one-GPU box.  The measured configuration is nccl (= RCCL over xGMI), one rank per GPU.
-    backend = os.environ.get("CLIVE2_BENCH_BACKEND", "nccl")
-    if os.environ.get("CLIVE2_BENCH_SHARE_GPU") == "1":
-        local_rank = 0
-    # a launcher may expose one GPU per rank (HIP_VISIBLE_DEVICES=<rank>): then the rank's GPU is device 0
-    local_rank %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    import numpy as np
-    import clive2_amd as c2
-    from clive2_amd.renderer import Renderer, make_seeds
-
+    # CLIVE2_BENCH_SHARE_GPU=1 (rehearsal only, NOT used by the driver) would put every rank on device 0;
+    # RCCL refuses two ranks on one device, so a one-GPU box can only rehearse N = 1.
     W, H = args.width, args.height
-    scene, scene_desc = build_scene(args.scene, W, H)
-    r = Renderer(scene, seeds=make_seeds(W * H, rank=rank), device=local_rank)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    r.set_levels_per_launch(args.levels_per_launch)
-    r.set_traversal_mode(args.traversal_mode)
-    r.set_pipelining(args.pipelining)
-
-    # untimed: warm-up (also the counting pass that measures N_node / N_tri per ray)
-    r.set_counting(True)
-    r.run_samples(max(args.warmup, 1))
-    cw = r.counters()
-    n_node = cw["box_tests"] / max(cw["counted_rays"], 1)
-    n_tri = cw["tri_tests"] / max(cw["counted_rays"], 1)
-    r.set_counting(False)
-    r.reduce_accumulators()          # untimed: creates the RCCL communicator and its buffers before the clock starts
-    r.reset_counters()
-    r.reset_accumulators()
-    r.set_profiling(1)               # timed region: HIP events around the connection-ray traversal launch only
-    if args.debug_flags:
-        r.set_debug_flags(args.debug_flags)
-
-    barrier()
-    t0 = time.perf_counter()
-    r.run_samples(args.steps)
-    r.reduce_accumulators()
-    barrier()
-    dt = time.perf_counter() - t0
-
-    c = r.counters()
-    rays_local = c["rays"]
-    # untimed: per-stage breakdown (HIP events around every launch) over a few more samples, in serial
-    # order on one stream -- with the sample pipeline on, spans of the two streams overlap and a
-    # stage's span includes whatever ran beside it
-    n_break = min(args.steps, 8)
-    r.reset_counters()
-    r.set_profiling(2)
-    r.set_pipelining(False)
-    r.run_samples(n_break)
-    cb = r.counters()
-    r.set_profiling(0)
-    r.set_pipelining(args.pipelining)
-    if world > 1:
-        t = torch.tensor([float(rays_local), dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        tmax = t.clone()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        rays_total, dt = t[0].item(), tmax[1].item()
-    else:
-        rays_total = float(rays_local)
+    res = run_workload(args, args.scene, W, H, args.steps, args.warmup, rank, local_rank, world, with_comm=world > 1)
 
     if rank == 0:
-        img, wts, cnt, _ = r.read_accumulators()
-        assert np.isfinite(img).all() and (cnt >= args.steps * world).all(), "accumulators corrupt"
-        b_ray = 48.0 + 32.0 * n_node + 36.0 * n_tri
-        stages = {k[3:]: round(cb[k] / n_break, 4) for k in cb if k.startswith("ms_")}
-        # the roofline kernel: the connection-ray traversal launch (70 % of all rays, one launch per
-        # sample), timed with HIP events on the renderer's stream inside the timed region
-        k_ms, k_rays, k_launches = c["ms_traverse_conn"], c["rays_traverse_conn"], c["launches_traverse_conn"]
-        k_name = "k_traverse_conn" if args.traversal_mode == 1 or (args.traversal_mode == 0 and args.scene == "cornell") \
-            else "k_traverse_persistent<ConnRaySource>"
-        achieved = (k_rays * b_ray) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic(k_name) if args.scene == "cornell" and (W, H) == (1920, 1080) else (None, None)
-        # what actually bounds the kernel on this scene (the tree is LDS-resident): VALU issue.  Wave-instructions
-        # per launch from the committed SQ counters x the measured issue cost (tools/valu_rate.hip: 2.3 cycles
-        # per fp32 wave-instruction; divides dearer, so this is a floor) over 1024 SIMDs at the 2.4 GHz clock,
-        # against the duration of the launch running alone
-        valu = None
-        n_valu = measured_valu(k_name) if args.scene == "cornell" and (W, H) == (1920, 1080) else None
-        if n_valu and cb["ms_traverse_conn"] > 0:
-            issue_ms = n_valu * 2.3 / (1024 * 2.4e9) * 1e3
-            alone_ms = cb["ms_traverse_conn"] / max(cb["launches_traverse_conn"], 1)
-            valu = {"kernel": k_name, "wave_insts_per_launch": n_valu, "issue_floor_ms": round(issue_ms, 4),
-                    "launch_alone_ms": round(alone_ms, 4), "frac": round(issue_ms / alone_ms, 4),
-                    "source": "profiles/r01_final_pmc_sq.txt (SQ_INSTS_VALU) x 2.3 cycles (tools/valu_rate.hip)"}
         out = {
             "metric": "Mrays/sec (whole node) + HBM GB/s, 1080p Cornell box, 1/2/4/8 MI355X",
-            "value": round(rays_total / dt / 1e6, 2),
+            "value": round(res["rays_total"] / res["dt"] / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "ms_per_step": round(res["dt"] / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{scene_desc} {W}x{H}, BDPT{' diffuse-only' if args.scene == 'cornell' else ''}, "
+            "config": {"workload": f"{res['scene_desc']} {W}x{H}, BDPT{' diffuse-only' if args.scene == 'cornell' else ''}, "
                                    f"{args.steps} spp per GPU", "width": W, "height": H,
-                       "rays_per_pixel_sample": round(rays_local / (args.steps * W * H), 3),
-                       "parallelism": f"sample-split x{world}, one {'RCCL' if backend == 'nccl' else backend} all-reduce of the accumulators"},
-            "hbm_gbs": {"kernel": k_name, "algorithmic": round(achieved, 1),
-                        "measured_pmc": round(traffic / (k_ms / max(k_launches, 1) * 1e-3) / 1e9, 1) if traffic else None},
-            "roofline": {"bound": "hbm", "kernel": k_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "bytes_per_ray": round(b_ray, 1), "n_node": round(n_node, 3), "n_tri": round(n_tri, 3),
-                         "rays_per_launch": round(k_rays / max(k_launches, 1)),
-                         "avg_launch_ms": round(k_ms / max(k_launches, 1), 4),
-                         # the same launch with nothing beside it (serial breakdown pass below)
-                         "avg_launch_ms_serial": round(cb["ms_traverse_conn"] / max(cb["launches_traverse_conn"], 1), 4),
-                         "frac_serial": round((cb["rays_traverse_conn"] * b_ray) / max(cb["ms_traverse_conn"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
-                         "sample_pipeline_stages": args.pipelining},
-            "stage_ms_per_step_serial": stages,
-            "valu": valu,
+                       "rays_per_pixel_sample": round(res["rays_local"] / (args.steps * W * H), 3),
+                       "parallelism": f"sample-split x{world}, one in-place RCCL all-reduce of the accumulators"
+                                      if world > 1 else "one GPU (no collective)"},
+            "roofline": res["roofline"],
+            "stage_ms_per_step_serial": res["stages"],
         }
+        if world == 1 and not args.no_mesh and args.scene == "cornell":
+            # second workload of the same line: the config-3 mesh scene, where the tree (1,781 boxes, 5,136
+            # triangles) is read through the caches and the bytes formula is a memory statement
+            m = run_workload(args, "glass", W, H, args.mesh_steps, 4, 0, local_rank, 1, with_comm=False)
+            out["roofline_mesh"] = dict(m["roofline"], workload=f"{m['scene_desc']} {W}x{H}, {args.mesh_steps} spp",
+                                        mrays_per_s=round(m["rays_total"] / m["dt"] / 1e6, 2),
+                                        ms_per_step=round(m["dt"] / args.mesh_steps * 1e3, 3),
+                                        stage_ms_per_step_serial=m["stages"])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_width, args.cpu_height, args.cpu_samples)
         print(json.dumps(out), flush=True)
-
-    r.close()
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -9,12 +9,20 @@ import subprocess
 
 import numpy as np
 
+import glob
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libclive2_amd.so")
-_SOURCES = [os.path.join(_PKG, "csrc", n) for n in
-            ("renderer_api.hip", "kernels.hpp", "connect_resolve.hpp", "bvh_traverse.hpp", "bvh_builder.hpp", "bsdf.hpp",
-             "vecmath.hpp", "detmath.hpp")]
+# the test variant additionally carries the second implementation of the resolve stage
+# (csrc/connect_resolve_wide.hpp, -DCL2_TEST_VARIANT): a cross-check for tests, not shipped code
+TEST_LIB_PATH = os.path.join(_PKG, "libclive2_amd_test.so")
+_MAIN_SOURCE = os.path.join(_PKG, "csrc", "renderer_api.hip")
 _HEADER = os.path.join(os.path.dirname(_PKG), "include", "clive2_amd.h")
+
+
+def _sources():
+    """Everything the translation unit includes: every file under csrc/ plus the public header."""
+    return sorted(glob.glob(os.path.join(_PKG, "csrc", "*.hip")) + glob.glob(os.path.join(_PKG, "csrc", "*.hpp"))) + [_HEADER]
 
 # -ffp-contract=off / no fast-math: every float op of the kernels rounds once, in source order.
 # -fno-slp-vectorize: packed fp32 VALU ops (v_pk_mul/add_f32) issue at half the rate of scalar ones on
@@ -39,80 +47,80 @@ class Counters(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class Organisation(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("tree_in_lds", "persistent_subpaths", "persistent_connections", "two_tris_per_step",
+                                         "n_records", "n_lds_records", "n_top_renumbered", "lds_triangles",
+                                         "levels_per_launch", "paths_share", "pipeline_stages", "pad")] + [("tree_bytes", C.c_int64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad"}
+
+
 EXPORTS = [
     "cl2_create", "cl2_destroy", "cl2_last_error", "cl2_abi_version", "cl2_build_bvh", "cl2_upload_scene", "cl2_set_seeds",
     "cl2_get_seeds", "cl2_make_light_rays", "cl2_make_camera_rays", "cl2_trace_light_rays",
     "cl2_trace_camera_rays", "cl2_join_paths", "cl2_finalize_samples", "cl2_gather_light_image",
     "cl2_process_images", "cl2_run_samples", "cl2_set_levels_per_launch", "cl2_set_traversal_mode", "cl2_set_pipelining", "cl2_read_accumulators", "cl2_reset_accumulators",
-    "cl2_read_accumulators_packed", "cl2_write_accumulators_packed", "cl2_copy_accumulators_to_device",
-    "cl2_copy_accumulators_from_device", "cl2_set_profiling", "cl2_set_counting", "cl2_set_debug_flags", "cl2_read_counters",
+    "cl2_read_accumulators_packed", "cl2_write_accumulators_packed", "cl2_device_count", "cl2_synchronize",
+    "cl2_comm_unique_id_bytes", "cl2_comm_get_unique_id", "cl2_comm_init_rank", "cl2_reduce_accumulators",
+    "cl2_comm_allreduce_f64", "cl2_comm_destroy", "cl2_import_sample_images", "cl2_query_organisation", "cl2_set_profiling", "cl2_set_counting", "cl2_set_debug_flags", "cl2_read_counters",
     "cl2_reset_counters", "cl2_selftest_exact_math", "cl2_export_rays", "cl2_export_paths", "cl2_export_aggregators",
     "cl2_export_sample_images", "cl2_probe_traverse", "cl2_probe_math", "cl2_probe_bounce",
 ]
 
 
-def needs_build():
-    if not os.path.exists(LIB_PATH):
+def _path(variant):
+    if variant not in (None, "test"):
+        raise ValueError("library variant must be None or 'test'")
+    return TEST_LIB_PATH if variant == "test" else LIB_PATH
+
+
+def needs_build(variant=None):
+    path = _path(variant)
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in _SOURCES + [_HEADER])
+    t = os.path.getmtime(path)
+    return any(os.path.getmtime(s) > t for s in _sources())
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, variant=None):
     """Cross-compile the HIP library for gfx950 with hipcc (works without a GPU)."""
-    if not force and not needs_build():
-        return LIB_PATH
-    cmd = ["hipcc"] + HIPCC_FLAGS + [_SOURCES[0], "-o", LIB_PATH]
+    path = _path(variant)
+    if not force and not needs_build(variant):
+        return path
+    cmd = ["hipcc"] + HIPCC_FLAGS + (["-DCL2_TEST_VARIANT"] if variant == "test" else []) + [_MAIN_SOURCE, "-o", path]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RendererError("hipcc failed:\n" + res.stdout)
     if verbose:
         print(" ".join(cmd))
-    return LIB_PATH
+    return path
 
 
-_lib = None
+_libs = {}
 
 
-def _share_hip_runtime_with_torch():
-    """One HIP runtime per process.  The PyTorch-ROCm wheel ships its own `libamdhip64.so` (soname
-    `libamdhip64.so.7`, found through torch's rpath), the library links `/opt/rocm`'s of the same
-    soname.  Whichever is loaded first serves every later request for that SONAME, but torch asks by
-    file name: if the system runtime came first, torch loads its own copy next to it, the second
-    runtime finds no GPU, and device pointers could not be exchanged with `torch.distributed`
-    anyway.  So when torch is installed, its runtime is loaded first (by path, without importing
-    torch) and both sides share it.  CLIVE2_SYSTEM_HIP=1 keeps the system runtime (no torch interop)."""
-    import sys
-    if os.environ.get("CLIVE2_SYSTEM_HIP") == "1" or "torch" in sys.modules:
-        return
-    try:
-        import importlib.util
-        spec = importlib.util.find_spec("torch")
-        if spec is None or not spec.submodule_search_locations:
-            return
-        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-        if os.path.exists(path):
-            C.CDLL(path, mode=C.RTLD_GLOBAL)
-    except OSError:
-        pass                                  # fall back to the runtime the library was linked against
-
-
-def lib():
-    """Load the library (never builds implicitly on a box without the sources' toolchain)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RendererError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+def lib(variant=None):
+    """Load the library (never builds implicitly: a box without the file has no render path).  It runs on
+    the ROCm runtime it was linked against (/opt/rocm); nothing of torch is loaded or needed."""
+    if variant not in _libs:
+        path = _path(variant)
+        if not os.path.exists(path):
+            raise RendererError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the render path.")
-        _share_hip_runtime_with_torch()
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         L.cl2_last_error.restype = C.c_char_p
         L.cl2_last_error.argtypes = [C.c_void_p]
         L.cl2_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.cl2_destroy.argtypes = [C.c_void_p]
         L.cl2_destroy.restype = None
-        _lib = L
-    return _lib
+        L.cl2_comm_get_unique_id.argtypes = [C.c_void_p, C.c_size_t]
+        L.cl2_comm_init_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.cl2_comm_allreduce_f64.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]
+        for name in ("cl2_reduce_accumulators", "cl2_comm_destroy", "cl2_synchronize"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        _libs[variant] = L
+    return _libs[variant]
 
 
 def ptr(a):

@@ -584,7 +584,9 @@ constexpr int AGG_ROWS = 13;
 
 }  // namespace cl2
 #include "connect_resolve.hpp"
+#ifdef CL2_TEST_VARIANT
 #include "connect_resolve_wide.hpp"
+#endif
 namespace cl2 {
 
 // ---------------------------------------------------------------- K6: adaptive_finalize_samples

@@ -18,6 +18,7 @@
 #include "../../include/clive2_amd.h"
 #include "kernels.hpp"
 #include "bvh_builder.hpp"
+#include "comm_rccl.hpp"
 
 using namespace cl2;
 
@@ -66,6 +67,7 @@ struct cl2_renderer {
     float* d_light_areas = nullptr;
     MaterialDev* d_mats = nullptr;
     int n_mats = 0, light_count = 0;
+    int n_top = 0;                       // boxes of the top levels renumbered to the front of the record array (0: plain visit order)
     CameraRec cam{};
 
     // state
@@ -94,6 +96,11 @@ struct cl2_renderer {
     std::vector<hipEvent_t> event_pool;
 
     std::vector<void*> allocs;
+
+    // multi-GPU sample split: one RCCL communicator per handle (cl2_comm_init_rank)
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_nranks = 0;
+    double* d_comm_scratch = nullptr;    // [COMM_SCRATCH] doubles for cl2_comm_allreduce_f64
 };
 
 namespace {
@@ -128,10 +135,12 @@ int fail(cl2_renderer* r, int code, const std::string& msg) { r->err = msg; retu
 
 inline int grid_for(size_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
 
+// nullptr when no event can be created: the span is then simply not timed (profiling is best effort,
+// the launch itself is unaffected)
 hipEvent_t take_event(cl2_renderer* r) {
     if (!r->event_pool.empty()) { hipEvent_t e = r->event_pool.back(); r->event_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
 
@@ -139,10 +148,17 @@ struct Timed {   // records a HIP-event span around a launch when profiling is o
     cl2_renderer* r; int stage; hipStream_t st; hipEvent_t a = nullptr;
     Timed(cl2_renderer* r_, int stage_, hipStream_t st_) : r(r_), stage(stage_), st(st_) {
         const bool wanted = r->profiling >= 2 || (r->profiling == 1 && stage == ST_TRAVERSE_CONN);
-        if (wanted) { a = take_event(r); (void)hipEventRecord(a, st); }
+        if (wanted) {
+            a = take_event(r);
+            if (a && hipEventRecord(a, st) != hipSuccess) { r->event_pool.push_back(a); a = nullptr; }
+        }
     }
     ~Timed() {
-        if (a) { hipEvent_t b = take_event(r); (void)hipEventRecord(b, st); r->spans.push_back({a, b, stage}); }
+        if (!a) return;
+        hipEvent_t b = take_event(r);
+        if (b && hipEventRecord(b, st) == hipSuccess) { r->spans.push_back({a, b, stage}); return; }
+        r->event_pool.push_back(a);
+        if (b) r->event_pool.push_back(b);
     }
 };
 
@@ -329,13 +345,19 @@ int launch_resolve(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
         hipLaunchKernelGGL(k_connect_resolve<W>, dim3(grid_for(B)), dim3(BLOCK), 0, st, B, lp, cp, r->d_mats, r->d_tri_shade,   \
                            r->cam, r->d_cmask[cs], r->d_chit[cs], r->d_agg, r->d_light_image, r->d_uni, r->d_stats, r->debug_flags)
         // experiment switch: 0 (default) / 2 / 4 = one thread per pixel at 3 / 2 / 4 waves per SIMD; 7 = one wave per
-        // camera vertex (connect_resolve_wide.hpp: same results bit for bit, measured slower: 1.14 vs 0.93 ms)
+        // camera vertex (connect_resolve_wide.hpp: same results bit for bit, measured slower: 1.14 vs 0.93 ms; a second
+        // implementation kept as a cross-check, built only with -DCL2_TEST_VARIANT = libclive2_amd_test.so)
         const int occ = (r->debug_flags >> 4) & 7;
+#ifdef CL2_TEST_VARIANT
         if (occ == 7)
             hipLaunchKernelGGL(k_connect_resolve_wide, dim3((B + RW_PIX - 1) / RW_PIX), dim3(RW_BLOCK), 0, st, B, lp, cp, r->d_mats,
                                r->d_tri_shade, r->cam, r->d_cmask[cs], r->d_chit[cs], r->d_agg, r->d_light_image, r->d_uni,
                                r->d_stats, r->debug_flags);
-        else if (occ == 2) CL2_RESOLVE(2); else if (occ == 4) CL2_RESOLVE(4); else CL2_RESOLVE(3);
+        else
+#else
+        if (occ == 7) return fail(r, CL2_E_INVALID, "the one-wave-per-camera-vertex resolve kernel is only built into the test variant of the library");
+#endif
+        if (occ == 2) CL2_RESOLVE(2); else if (occ == 4) CL2_RESOLVE(4); else CL2_RESOLVE(3);
 #undef CL2_RESOLVE
     }
     HIP_TRY(r, hipGetLastError());
@@ -381,7 +403,7 @@ int need_scene(cl2_renderer* r) {
 
 extern "C" {
 
-int cl2_abi_version(void) { return 1; }
+int cl2_abi_version(void) { return 2; }
 
 int cl2_build_bvh(const double* tri_min, const double* tri_max, int64_t n_triangles, int max_members, int max_depth,
                   void* out_boxes, int64_t box_capacity, int64_t* n_boxes_out, int64_t* out_perm) {
@@ -488,6 +510,7 @@ int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_render
 void cl2_destroy(cl2_renderer* r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
+    if (r->comm) (void)cl2_comm_destroy(r);
     if (r->stream) (void)hipStreamSynchronize(r->stream);
     if (r->stream_conn) (void)hipStreamSynchronize(r->stream_conn);
     if (r->stream_res) (void)hipStreamSynchronize(r->stream_res);
@@ -548,12 +571,22 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     }
     const int n_records = subtree[0];
     std::vector<int> rec_index(n_boxes, -1);
+    // `pending[i]`: entries on the reference's stack underneath box i when it is popped.  The reference's loop
+    // runs `while (stack_ptr > 0 && stack_ptr < 64)` (trace.metal:149): a walk that enters an inner box with 62
+    // entries pending pushes to 64 and ENDS there, whatever is still unvisited (quirk Q18).  The stackless walk has
+    // no such limit, so a tree that could reach it is refused instead of being rendered differently; the
+    // reference's builder stops splitting at 32 pending boxes (bvh.py:294, Q13), far below.
+    std::vector<int> pending(n_boxes, 0);
     rec_index[0] = 0;
     for (int i = 0; i < n_boxes; i++) {                  // parents before children: their record index is known
         const BoxRec& b = boxes[i];
         if (b.right == 0) {
+            if (pending[i] + 2 >= 64)
+                return fail(r, CL2_E_INVALID, "tree too deep: the reference's 64-entry traversal stack would overflow at box " + std::to_string(i));
             rec_index[b.left + 1] = rec_index[i] + 1;                            // right child: adjacent
             rec_index[b.left] = rec_index[i] + 1 + subtree[b.left + 1];          // left child: after the right subtree
+            pending[b.left + 1] = pending[i] + 1;                                // popped first, its sibling waits below it
+            pending[b.left] = pending[i];
         }
     }
     // ---- record numbering.  Small trees: plain visit order.  Trees larger than the LDS window: the
@@ -665,6 +698,7 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     r->bvh.n_lds_nodes = std::min(n_records, LDS_NODE_CAP);
     r->bvh.lds_tris = n_tris <= LDS_TRI_CAP ? 1 : 0;
     r->n_mats = n_mats; r->light_count = light_count; r->cam = cam;
+    r->n_top = n_top;
     r->scene_ok = true;
     r->paths_share = 0;                  // re-tune the stage shares for the new scene
     r->levels_auto = 0;
@@ -857,17 +891,118 @@ static int acc_copy(cl2_renderer* r, void* dst, const void* src, size_t n_floats
     if (!r || !dst || !src) return CL2_E_INVALID;
     if (n_floats != 8 * (size_t)r->B) return fail(r, CL2_E_INVALID, "packed accumulators hold 8*W*H floats");
     HIP_TRY(r, hipSetDevice(r->device));
-    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    TRY(drain(r));
     HIP_TRY(r, hipMemcpy(dst, src, n_floats * sizeof(float), kind));
-    // a device-to-device hipMemcpy may return before it has run; the caller hands the buffer to RCCL
-    // (another stream) right away, so make it complete here
-    if (kind == hipMemcpyDeviceToDevice) HIP_TRY(r, hipDeviceSynchronize());
     return CL2_OK;
 }
 int cl2_read_accumulators_packed(cl2_renderer* r, float* dst, size_t n) { return acc_copy(r, dst, r ? r->d_acc : nullptr, n, hipMemcpyDeviceToHost); }
 int cl2_write_accumulators_packed(cl2_renderer* r, const float* src, size_t n) { return acc_copy(r, r ? r->d_acc : nullptr, src, n, hipMemcpyHostToDevice); }
-int cl2_copy_accumulators_to_device(cl2_renderer* r, void* dst, size_t n) { return acc_copy(r, dst, r ? r->d_acc : nullptr, n, hipMemcpyDeviceToDevice); }
-int cl2_copy_accumulators_from_device(cl2_renderer* r, const void* src, size_t n) { return acc_copy(r, r ? r->d_acc : nullptr, src, n, hipMemcpyDeviceToDevice); }
+
+// ---------------------------------------------------------------- multi-GPU: RCCL behind the C ABI
+namespace {
+constexpr int COMM_SCRATCH = 16;
+#define RCCL_TRY(r, api, expr)                                                                    \
+    do {                                                                                          \
+        ncclResult_t e_ = (expr);                                                                 \
+        if (e_ != ncclSuccess) {                                                                  \
+            (r)->err = std::string(#expr) + ": " + (api)->GetErrorString(e_);                     \
+            return CL2_E_COMM;                                                                    \
+        }                                                                                         \
+    } while (0)
+}  // namespace
+
+int cl2_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int cl2_synchronize(cl2_renderer* r) {
+    if (!r) return CL2_E_INVALID;
+    HIP_TRY(r, hipSetDevice(r->device));
+    TRY(drain(r));
+    HIP_TRY(r, hipDeviceSynchronize());
+    return CL2_OK;
+}
+
+int cl2_comm_unique_id_bytes(void) { return (int)sizeof(ncclUniqueId); }
+
+int cl2_comm_get_unique_id(void* out, size_t n_bytes) {
+    if (!out || n_bytes != sizeof(ncclUniqueId)) { g_create_error = "cl2_comm_get_unique_id: the id is cl2_comm_unique_id_bytes() long"; return CL2_E_INVALID; }
+    std::string why;
+    RcclApi* api = rccl_api(why);
+    if (!api) { g_create_error = why; return CL2_E_COMM; }
+    ncclUniqueId id;
+    const ncclResult_t e = api->GetUniqueId(&id);
+    if (e != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + api->GetErrorString(e); return CL2_E_COMM; }
+    std::memcpy(out, &id, sizeof id);
+    return CL2_OK;
+}
+
+int cl2_comm_init_rank(cl2_renderer* r, int nranks, int rank, const void* unique_id, size_t n_bytes) {
+    if (!r) return CL2_E_INVALID;
+    if (!unique_id || n_bytes != sizeof(ncclUniqueId)) return fail(r, CL2_E_INVALID, "unique id must be cl2_comm_unique_id_bytes() long");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(r, CL2_E_INVALID, "need 0 <= rank < nranks");
+    if (r->comm) return fail(r, CL2_E_STATE, "this renderer already has a communicator (cl2_comm_destroy first)");
+    std::string why;
+    RcclApi* api = rccl_api(why);
+    if (!api) return fail(r, CL2_E_COMM, why);
+    HIP_TRY(r, hipSetDevice(r->device));
+    TRY(drain(r));
+    if (!r->d_comm_scratch) TRY(dev_alloc(r, &r->d_comm_scratch, (size_t)COMM_SCRATCH));
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(r, api, api->CommInitRank(&comm, nranks, id, rank));
+    r->comm = comm; r->comm_rank = rank; r->comm_nranks = nranks;
+    return CL2_OK;
+}
+
+/* The collective of SURVEY.md 8e: in place, on the stream every accumulating kernel ran on (drained
+ * first: with the sample pipeline the accumulation runs on stream_res). */
+int cl2_reduce_accumulators(cl2_renderer* r) {
+    if (!r) return CL2_E_INVALID;
+    if (!r->comm) return fail(r, CL2_E_STATE, "no communicator (call cl2_comm_init_rank first)");
+    std::string why;
+    RcclApi* api = rccl_api(why);
+    if (!api) return fail(r, CL2_E_COMM, why);
+    HIP_TRY(r, hipSetDevice(r->device));
+    TRY(drain(r));
+    RCCL_TRY(r, api, api->AllReduce(r->d_acc, r->d_acc, 8 * (size_t)r->B, ncclFloat, ncclSum, r->comm, r->stream));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    return CL2_OK;
+}
+
+/* n <= 16 host doubles, summed (op 0) or maximised (op 1) over the ranks, in place: barrier, the
+ * max-over-ranks clock and the whole-job ray tally of bench.py / render.py. */
+int cl2_comm_allreduce_f64(cl2_renderer* r, double* values, int n, int op) {
+    if (!r || !values) return CL2_E_INVALID;
+    if (n < 1 || n > COMM_SCRATCH || (op != 0 && op != 1)) return fail(r, CL2_E_INVALID, "allreduce_f64: 1..16 values, op 0 (sum) or 1 (max)");
+    if (!r->comm) return fail(r, CL2_E_STATE, "no communicator (call cl2_comm_init_rank first)");
+    std::string why;
+    RcclApi* api = rccl_api(why);
+    if (!api) return fail(r, CL2_E_COMM, why);
+    HIP_TRY(r, hipSetDevice(r->device));
+    TRY(drain(r));
+    HIP_TRY(r, hipMemcpyAsync(r->d_comm_scratch, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, r->stream));
+    RCCL_TRY(r, api, api->AllReduce(r->d_comm_scratch, r->d_comm_scratch, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, r->comm, r->stream));
+    HIP_TRY(r, hipMemcpyAsync(values, r->d_comm_scratch, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    return CL2_OK;
+}
+
+int cl2_comm_destroy(cl2_renderer* r) {
+    if (!r) return CL2_E_INVALID;
+    if (!r->comm) return CL2_OK;
+    std::string why;
+    RcclApi* api = rccl_api(why);
+    if (!api) return fail(r, CL2_E_COMM, why);
+    (void)hipSetDevice(r->device);
+    (void)drain(r);                       // nothing of ours may be in flight on the communicator's stream
+    ncclComm_t comm = r->comm;
+    r->comm = nullptr; r->comm_nranks = 0; r->comm_rank = 0;
+    RCCL_TRY(r, api, api->CommDestroy(comm));
+    return CL2_OK;
+}
 
 int cl2_set_profiling(cl2_renderer* r, int level) {
     if (!r) return CL2_E_INVALID;
@@ -934,6 +1069,24 @@ int cl2_set_traversal_mode(cl2_renderer* r, int mode) {
     if (mode < 0 || mode > 3) return fail(r, CL2_E_INVALID, "traversal mode must be 0 (auto), 1 (fused), 2 (persistent) or 3 (fused subpaths, persistent connection rays)");
     r->traversal_mode = mode;
     r->paths_share = 0;
+    return CL2_OK;
+}
+int cl2_query_organisation(cl2_renderer* r, cl2_organisation* out) {
+    if (!r || !out) return CL2_E_INVALID;
+    if (!r->scene_ok) return fail(r, CL2_E_STATE, "no scene uploaded (call cl2_upload_scene first)");
+    std::memset(out, 0, sizeof *out);
+    out->tree_in_lds = tree_in_lds(r) ? 1 : 0;
+    out->persistent_subpaths = split_paths(r) ? 1 : 0;
+    out->persistent_connections = split_conn(r) ? 1 : 0;
+    out->two_tris_per_step = two_tris_per_step(r) ? 1 : 0;
+    out->n_records = r->bvh.n_nodes;
+    out->n_lds_records = r->bvh.n_lds_nodes;
+    out->n_top_renumbered = r->n_top;
+    out->lds_triangles = r->bvh.lds_tris;
+    out->levels_per_launch = split_paths(r) ? 1 : effective_levels(r);
+    out->paths_share = r->paths_share;
+    out->pipeline_stages = pipeline_stages(r);
+    out->tree_bytes = (int64_t)r->bvh.n_nodes * 32 + (int64_t)r->bvh.n_tris * 48;
     return CL2_OK;
 }
 int cl2_set_debug_flags(cl2_renderer* r, int flags) { if (!r) return CL2_E_INVALID; r->debug_flags = flags; return CL2_OK; }
@@ -1020,6 +1173,18 @@ int cl2_export_sample_images(cl2_renderer* r, float* fin4, float* light4, float*
     if (light4) HIP_TRY(r, hipMemcpy(light4, r->d_light_image, B * sizeof(float4), hipMemcpyDeviceToHost));
     if (sw) HIP_TRY(r, hipMemcpy(sw, r->d_sample_w, B * sizeof(float), hipMemcpyDeviceToHost));
     if (uni4) HIP_TRY(r, hipMemcpy(uni4, r->d_uni, B * sizeof(float4), hipMemcpyDeviceToHost));
+    return CL2_OK;
+}
+
+int cl2_import_sample_images(cl2_renderer* r, const float* fin4, const float* light4, const float* sw, const float* uni4, size_t n_pixels) {
+    STAGE_PROLOGUE(r);
+    if (n_pixels != (size_t)r->B) return fail(r, CL2_E_INVALID, "n_pixels must equal W*H");
+    TRY(drain(r));
+    const size_t B = r->B;
+    if (fin4) HIP_TRY(r, hipMemcpy(r->d_finalized, fin4, B * sizeof(float4), hipMemcpyHostToDevice));
+    if (light4) HIP_TRY(r, hipMemcpy(r->d_light_image, light4, B * sizeof(float4), hipMemcpyHostToDevice));
+    if (sw) HIP_TRY(r, hipMemcpy(r->d_sample_w, sw, B * sizeof(float), hipMemcpyHostToDevice));
+    if (uni4) HIP_TRY(r, hipMemcpy(r->d_uni, uni4, B * sizeof(float4), hipMemcpyHostToDevice));
     return CL2_OK;
 }
 

@@ -1,11 +1,76 @@
 """Multi-GPU sample split: every rank renders its own samples of the replicated
 scene; the accumulators -- pure sums (renderer.py:269-273) -- are combined by ONE sum all-reduce
-of the packed planar buffer [8][H*W] float32 (66 MB at 1080p).  On GPUs the process group is
-`nccl` (= RCCL over xGMI); the same code path runs with `gloo` on CPUs for tests.
+of the packed planar buffer [8][H*W] float32 (66 MB at 1080p).  On GPUs that is an in-place RCCL
+all-reduce inside the library (`cl2_comm_init_rank` / `cl2_reduce_accumulators`, include/clive2_amd.h);
+this module holds the host side of it: the rank environment, the sample partition, and the hand-over
+of RCCL's unique id from rank 0 to the other ranks of the node through a file.  torch is not needed.
 """
 import os
+import tempfile
+import time
 
 import numpy as np
+
+
+def rendezvous_path():
+    """Where rank 0 leaves the communicator id for the other ranks of this job (one node).
+    `CLIVE2_RENDEZVOUS_FILE` names it explicitly (any process spawner); otherwise it is derived from what
+    all ranks of one launch share and no other launch does: MASTER_ADDR/MASTER_PORT, the launcher's
+    run id and the launcher's pid (the ranks' common parent under `python -m torch.distributed.run`)."""
+    explicit = os.environ.get("CLIVE2_RENDEZVOUS_FILE")
+    if explicit:
+        return explicit
+    key = "_".join(str(x) for x in (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
+                                    os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid(), os.getuid()))
+    return os.path.join(os.environ.get("CLIVE2_RENDEZVOUS_DIR", tempfile.gettempdir()), f"clive2_rccl_id_{key}")
+
+
+def exchange_unique_id(rank, world_size, make_id, n_bytes, path=None, timeout=180.0):
+    """Rank 0 calls `make_id()` (-> `n_bytes` bytes) and publishes them atomically (write + rename);
+    the others poll for the file.  Returns the id on every rank.  Rank 0 removes the file with
+    `finish_exchange` once every rank has joined the communicator (comm_init returns only then)."""
+    path = path or rendezvous_path()
+    if world_size == 1:
+        return make_id()
+    if rank == 0:
+        uid = bytes(make_id())
+        if len(uid) != n_bytes:
+            raise ValueError(f"unique id has {len(uid)} bytes, expected {n_bytes}")
+        tmp = f"{path}.tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            # a file left behind by a crashed job with the same key would be much older than this process
+            if time.time() - os.path.getmtime(path) < 600.0:
+                with open(path, "rb") as f:
+                    uid = f.read()
+                if len(uid) == n_bytes:
+                    return uid
+        except OSError:
+            pass
+        if time.monotonic() > deadline:
+            raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout:.0f} s (is rank 0 alive?)")
+        time.sleep(0.02)
+
+
+def finish_exchange(rank, path=None):
+    if rank == 0:
+        try:
+            os.unlink(path or rendezvous_path())
+        except OSError:
+            pass
+
+
+def join_communicator(renderer, rank, world_size, path=None, timeout=180.0):
+    """The whole bootstrap for one rank: id from rank 0, `comm_init` (collective), clean-up."""
+    n = renderer._L.cl2_comm_unique_id_bytes()
+    uid = exchange_unique_id(rank, world_size, renderer.comm_unique_id, n, path=path, timeout=timeout)
+    renderer.comm_init(rank, world_size, uid)
+    finish_exchange(rank, path)
 
 
 def rank_info():
@@ -21,8 +86,10 @@ def samples_for_rank(total_samples, rank, world_size):
 
 
 def allreduce_packed_host(packed, group=None):
-    """Sum a packed accumulator array over the group through host memory (gloo, or any backend
-    that accepts CPU tensors).  Returns a new float32 numpy array."""
+    """CPU-side rehearsal of the reduce for tests (tests/test_distributed_cpu.py: world_size-2 gloo
+    group, the oracle standing in for the GPU): sums a packed accumulator array over a
+    torch.distributed group through host memory.  The GPU path does not come here: it is
+    `Renderer.reduce_accumulators` (RCCL inside the library).  Returns a new float32 numpy array."""
     import torch
     import torch.distributed as dist
     t = torch.from_numpy(np.ascontiguousarray(packed, dtype=np.float32).copy())

@@ -2,8 +2,9 @@
 instead of a cv2 window.  Every frame is its own scene (the camera quad is part of the geometry,
 `load.py:261-271`) and its own Renderer, exactly as in the reference's frame loop (`movie.py:29-55`).
 
-Frames are independent units: under `python -m torch.distributed.run --nproc-per-node N -m
-clive2_amd.movie ...` rank r renders frames r, r+N, r+2N, ... on its own GPU with no collective.
+Frames are independent units: with one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment, e.g. under `python -m torch.distributed.run --nproc-per-node N -m clive2_amd.movie ...`)
+rank r renders frames r, r+N, r+2N, ... on its own GPU with no collective.
 
     python -m clive2_amd.movie --scene empty --width 1280 --height 720 --samples 15 --movie-frames 120
 """
@@ -25,9 +26,10 @@ def frames_for_rank(start_frame, total_frames, rank, world):
 
 
 def save_frame(path, image):
-    """`image` is the Renderer's tone-mapped uint8 BGR picture with row 0 at the bottom of the film."""
+    """`image` is the Renderer's tone-mapped uint8 BGR picture; row 0 is the TOP of the picture (the film
+    sits behind the pinhole), exactly what the reference shows with cv2 (movie.py:45-47): BGR -> RGB only."""
     from PIL import Image
-    Image.fromarray(np.ascontiguousarray(image[::-1, :, ::-1])).save(path)
+    Image.fromarray(np.ascontiguousarray(image[:, :, ::-1])).save(path)
 
 
 def main(argv=None):

@@ -3,16 +3,18 @@ instead of opening a cv2 window (display code is out of scope).
 
     python -m clive2_amd.render --scene empty --width 1280 --height 720 --samples 64 --out cornell.png
 
-Several GPUs: `python -m torch.distributed.run --nproc-per-node N -m clive2_amd.render ...` -- every
-rank renders its share of the samples of the same frame with its own seeds, ONE sum all-reduce of the
-accumulators (RCCL) follows, rank 0 writes the picture.
+Several GPUs: start one process per GPU with RANK / LOCAL_RANK / WORLD_SIZE in the environment (e.g.
+`python -m torch.distributed.run --nproc-per-node N -m clive2_amd.render ...`; any spawner will do, torch
+itself is not used) -- every rank renders its share of the samples of the same frame with its own seeds,
+ONE in-place RCCL all-reduce of the accumulators follows, rank 0 writes the picture.
 """
 import argparse
 import time
 
 import numpy as np
 
-from .distributed import rank_info, samples_for_rank
+from . import _native
+from .distributed import rank_info, samples_for_rank, join_communicator
 from .renderer import Renderer, RendererError, make_seeds
 from .scene import create_scene_from_preset
 
@@ -29,33 +31,53 @@ def main(argv=None):
     args = ap.parse_args(argv)
 
     rank, local_rank, world = rank_info()
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        local_rank %= max(torch.cuda.device_count(), 1)       # one visible GPU per rank: it is device 0
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     scene = create_scene_from_preset(args.scene, pixel_width=args.width, pixel_height=args.height)
-    device = local_rank if world > 1 else args.device
+    if world > 1:
+        # one GPU per rank; a launcher that exposes a single GPU to each rank makes it device 0
+        device = local_rank % max(_native.lib().cl2_device_count(), 1)
+    else:
+        device = args.device
     renderer = Renderer(scene, seeds=make_seeds(args.width * args.height, rank=rank), device=device)
+    if world > 1:
+        join_communicator(renderer, rank, world)
     t0 = time.time()
+    failure = None
     try:
         renderer.run_samples(samples_for_rank(args.samples, rank, world))
-    except (KeyboardInterrupt, RendererError):
-        if not args.save_on_quit:
-            raise
-    renderer.reduce_accumulators()
+    except (KeyboardInterrupt, RendererError) as e:
+        failure = e
+    if world > 1:
+        # Agree on the outcome BEFORE the collective: a rank that failed must not leave its peers blocked in
+        # the all-reduce, and a sum that lacks a rank's samples must not be mistaken for the picture.
+        # (A rank that died outright cannot answer; its peers then fail in RCCL when the launcher kills the job.)
+        try:
+            bad = renderer.allreduce_host([1.0 if failure is not None else 0.0], op="max")[0] > 0.0
+        except RendererError as e:
+            bad, failure = True, failure or e
+        if bad and not args.save_on_quit:
+            renderer.close()
+            if failure is not None:
+                raise failure
+            raise RendererError(f"[rank {rank}] another rank failed: the accumulators were not reduced")
+        if bad:
+            print(f"[rank {rank}] a rank stopped early: reducing what every rank has ({renderer.samples} samples here)")
+        renderer.reduce_accumulators()
+    elif failure is not None and not args.save_on_quit:
+        raise failure
     dt = time.time() - t0
     rays = renderer.counters()["rays"]
     print(f"[rank {rank}] rendering took {dt:.2f} seconds ({renderer.samples} samples, {rays / max(dt, 1e-9) / 1e6:.0f} Mrays/s)")
-    if world > 1:
-        dist.destroy_process_group()
     if rank != 0:
+        renderer.close()
         return 0
-    image = renderer.image                      # tone-mapped uint8, BGR, row 0 = bottom of the film
+    # Tone-mapped uint8, BGR.  The film sits BEHIND the pinhole, so the picture on it is already upright
+    # when read row 0 first (row 0 looks up at the ceiling light): the reference hands `renderer.image`
+    # to cv2 unflipped (render.py:35-37).  Only the channel order changes for a PNG (BGR -> RGB).
+    image = renderer.image
+    renderer.close()
     try:
         from PIL import Image
-        Image.fromarray(np.ascontiguousarray(image[::-1, :, ::-1])).save(args.out)
+        Image.fromarray(np.ascontiguousarray(image[:, :, ::-1])).save(args.out)
     except ImportError:
         np.save(args.out + ".npy", image)
     return 0

@@ -12,15 +12,15 @@ attributes as the reference class, so callers written against it (`render.py:26-
 * `gather_light_image` is a no-op synchronisation point: the t=1 light-image splat happens in
   `join_paths` with float atomics (the reference's 300-launch bitonic sort + host bincount,
   renderer.py:212-250, has no counterpart);
-* multi-GPU sample splitting: `reduce_accumulators()` sums the accumulators of all ranks of a
-  `torch.distributed` process group (RCCL over xGMI on GPUs).
+* multi-GPU sample splitting: `comm_init(rank, world, id)` + `reduce_accumulators()` sum the
+  accumulators of all ranks with one in-place RCCL all-reduce inside the library (no torch).
 """
 import ctypes as C
 
 import numpy as np
 
 from . import _native
-from ._native import RendererError, Counters, ptr
+from ._native import RendererError, Counters, Organisation, ptr
 from . import struct_types as st
 from .camera import tone_map
 from .constants import timed, MAX_PATH_LENGTH  # noqa: F401
@@ -41,11 +41,12 @@ def next_power_of_two(n):
 
 
 class Renderer:
-    def __init__(self, scene, kernel_path=None, seeds=None, device=0):
+    def __init__(self, scene, kernel_path=None, seeds=None, device=0, variant=None):
         # kernel_path is accepted for signature compatibility (the reference JIT-compiles
         # trace.metal from it, renderer.py:27-29); the HIP kernels are precompiled.
+        # variant="test" loads libclive2_amd_test.so (carries the cross-check resolve kernel).
         self._h = C.c_void_p()
-        self._L = _native.lib()
+        self._L = _native.lib(variant)
         self.scene = scene
         self.device = device
         self.pixel_width, self.pixel_height = scene.pixel_width, scene.pixel_height
@@ -192,24 +193,39 @@ class Renderer:
         a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
         self._check(self._L.cl2_write_accumulators_packed(self._h, ptr(a), C.c_size_t(a.size)), "write_packed")
 
-    def reduce_accumulators(self, group=None, always=False):
-        """All-reduce (sum) the accumulators over the ranks of a torch.distributed group.  On GPUs
-        the message stays in HBM (RCCL); with a CPU backend (gloo) it goes through the host.
-        A one-rank group is a no-op unless `always` (used to exercise the RCCL path on one GPU)."""
-        import torch
-        import torch.distributed as dist
-        if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always):
-            return
-        n = 8 * self.batch_size
-        if dist.get_backend(group) == "nccl":
-            t = torch.empty(n, dtype=torch.float32, device=f"cuda:{self.device}")
-            self._check(self._L.cl2_copy_accumulators_to_device(self._h, C.c_void_p(t.data_ptr()), C.c_size_t(n)), "acc->dev")
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            torch.cuda.synchronize(self.device)
-            self._check(self._L.cl2_copy_accumulators_from_device(self._h, C.c_void_p(t.data_ptr()), C.c_size_t(n)), "dev->acc")
-        else:
-            from .distributed import allreduce_packed_host
-            self.load_packed_accumulators(allreduce_packed_host(self.packed_accumulators(), group))
+    def comm_init(self, rank, world_size, unique_id):
+        """Join the RCCL communicator of the sample split (collective: returns when every rank has
+        called it).  `unique_id`: the bytes rank 0 got from `comm_unique_id()` and handed to everybody
+        (`clive2_amd.distributed.exchange_unique_id`)."""
+        uid = bytes(unique_id)
+        self._check(self._L.cl2_comm_init_rank(self._h, int(world_size), int(rank), uid, C.c_size_t(len(uid))), "cl2_comm_init_rank")
+        self.rank, self.world_size = int(rank), int(world_size)
+
+    def comm_unique_id(self):
+        n = self._L.cl2_comm_unique_id_bytes()
+        buf = C.create_string_buffer(n)
+        rc = self._L.cl2_comm_get_unique_id(buf, C.c_size_t(n))
+        if rc != 0:
+            msg = self._L.cl2_last_error(None)
+            raise RendererError(f"cl2_comm_get_unique_id failed ({rc}): {msg.decode() if msg else ''}")
+        return buf.raw
+
+    def reduce_accumulators(self):
+        """ONE in-place all-reduce (sum) of the packed accumulators over the communicator's ranks
+        (RCCL over xGMI); every rank then holds the sums.  Needs `comm_init`."""
+        self._check(self._L.cl2_reduce_accumulators(self._h), "cl2_reduce_accumulators")
+
+    def allreduce_host(self, values, op="sum"):
+        """Up to 16 host floats summed / maximised over the ranks (also the barrier of the job)."""
+        v = (C.c_double * len(values))(*[float(x) for x in values])
+        self._check(self._L.cl2_comm_allreduce_f64(self._h, v, len(values), {"sum": 0, "max": 1}[op]), "cl2_comm_allreduce_f64")
+        return list(v)
+
+    def comm_destroy(self):
+        self._check(self._L.cl2_comm_destroy(self._h), "cl2_comm_destroy")
+
+    def synchronize(self):
+        self._check(self._L.cl2_synchronize(self._h), "cl2_synchronize")
 
     # ---- counters / profiling ----
     def set_profiling(self, level=2):
@@ -250,6 +266,12 @@ class Renderer:
         self._check(self._L.cl2_read_counters(self._h, C.byref(c)), "read_counters")
         return c.as_dict()
 
+    def organisation(self):
+        """What the automatic launch-organisation choices came to for this scene (dict of cl2_organisation)."""
+        o = Organisation()
+        self._check(self._L.cl2_query_organisation(self._h, C.byref(o)), "query_organisation")
+        return o.as_dict()
+
     def reset_counters(self):
         self._check(self._L.cl2_reset_counters(self._h), "reset_counters")
 
@@ -276,6 +298,16 @@ class Renderer:
         self._check(self._L.cl2_export_sample_images(self._h, ptr(fin), ptr(light), ptr(sw), ptr(uni), C.c_size_t(B)),
                     "export_sample_images")
         return dict(finalized=fin, light=light, sample_weights=sw, unidirectional=uni)
+
+    def import_sample_images(self, finalized=None, light=None, sample_weights=None, unidirectional=None):
+        """Per-sample images from host arrays ((B,4) float32 / (B,) float32): lets `process_images` be
+        checked on its own against the reference's numpy code (tests/golden/renderer_glue.npz)."""
+        def f4(a):
+            return None if a is None else np.ascontiguousarray(a, dtype=np.float32).reshape(self.batch_size, 4)
+        fin, li, un = f4(finalized), f4(light), f4(unidirectional)
+        sw = None if sample_weights is None else np.ascontiguousarray(sample_weights, dtype=np.float32).reshape(self.batch_size)
+        self._check(self._L.cl2_import_sample_images(self._h, ptr(fin), ptr(li), ptr(sw), ptr(un), C.c_size_t(self.batch_size)),
+                    "import_sample_images")
 
     def probe_traverse(self, rays):
         rays = np.ascontiguousarray(rays, dtype=st.Ray)

@@ -30,6 +30,19 @@ class Scene:
         self.light_triangle_indices = light_triangle_indices
         self.camera_triangle_indices = camera_triangle_indices
 
+    def with_resolution(self, pixel_width, pixel_height):
+        """The same scene at another frame size of the SAME aspect ratio: the camera quad is part of the
+        geometry (load.py:261-271) and its size depends on the aspect ratio only, so nothing but the two
+        pixel counts of the camera record changes (create_scene at the new size gives the same bytes
+        otherwise) and the BVH need not be rebuilt."""
+        if pixel_width * self.pixel_height != pixel_height * self.pixel_width:
+            raise ValueError("with_resolution keeps the aspect ratio (the camera quad would change otherwise)")
+        cam = np.array(self.camera, copy=True)
+        cam["pixel_width"], cam["pixel_height"] = pixel_width, pixel_height
+        return Scene(self.device, pixel_width, pixel_height, cam, self.triangles, self.boxes, self.materials,
+                     self.light_triangles, self.light_counts, self.light_surface_areas,
+                     self.light_triangle_indices, self.camera_triangle_indices)
+
     def validate(self):
         """Host-side shape checks run before every upload (a bad index here would be an
         out-of-bounds access on the GPU)."""

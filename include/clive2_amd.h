@@ -34,7 +34,8 @@ enum {
     CL2_E_INVALID = -1,      /* bad argument / scene failed validation */
     CL2_E_HIP = -2,          /* HIP runtime error (see cl2_last_error) */
     CL2_E_STATE = -3,        /* call sequence error (e.g. no scene uploaded) */
-    CL2_E_NOMEM = -4
+    CL2_E_NOMEM = -4,
+    CL2_E_COMM = -5          /* RCCL error, or librccl could not be loaded (see cl2_last_error) */
 };
 
 /* Which subpath / ray buffer: reference `light_ray_buffer` / `camera_ray_buffer`,
@@ -132,12 +133,52 @@ int cl2_read_accumulators(cl2_renderer* r, float* summed_image /*H*W*3*/, float*
                           int32_t* summed_sample_counts /*H*W*/, float* unidirectional /*H*W*3*/, size_t n_pixels);
 int cl2_reset_accumulators(cl2_renderer* r);
 /* packed planar form [8][H*W] = image b,g,r | weights | unidirectional b,g,r | counts(float):
- * the message of the multi-GPU sum-reduce.  *_device take DEVICE pointers (e.g. a torch tensor's
- * data_ptr()) so RCCL can reduce without a host round trip. */
+ * the message of the multi-GPU sum-reduce, as host arrays (checkpointing, CPU-side tests). */
 int cl2_read_accumulators_packed(cl2_renderer* r, float* host_dst, size_t n_floats);
 int cl2_write_accumulators_packed(cl2_renderer* r, const float* host_src, size_t n_floats);
-int cl2_copy_accumulators_to_device(cl2_renderer* r, void* device_dst, size_t n_floats);
-int cl2_copy_accumulators_from_device(cl2_renderer* r, const void* device_src, size_t n_floats);
+
+/* -- multi-GPU sample split (the reference is single-device, src/renderer.py:281-291).
+ *    Samples are i.i.d. and the accumulators are pure sums (src/renderer.py:269-273): every rank
+ *    renders its own samples of the replicated scene with its own seed buffer, then ONE in-place RCCL
+ *    all-reduce (sum, float32) of the packed accumulators [8][H*W] combines them (66 MB at 1080p, over
+ *    xGMI).  One communicator per handle, one handle per GPU, one process (or thread) per handle.
+ *    librccl is loaded (dlopen) by the first of these calls; a failure is CL2_E_COMM, never fatal.
+ *
+ *      rank 0:  cl2_comm_get_unique_id(id)  -> hand the cl2_comm_unique_id_bytes() bytes to every rank
+ *               (file, socket, launcher: the caller's business; clive2_amd/distributed.py uses a file)
+ *      all   :  cl2_comm_init_rank(r, nranks, rank, id)      (collective: returns when all have called)
+ *               ... cl2_run_samples(r, n_rank) ...
+ *               cl2_reduce_accumulators(r)                  (collective; every rank then holds the sums)
+ *               cl2_comm_destroy(r)                         (also done by cl2_destroy) -- */
+int cl2_device_count(void);                          /* HIP devices visible to this process (0 on error) */
+int cl2_synchronize(cl2_renderer* r);                /* drains the handle's streams, then the device */
+int cl2_comm_unique_id_bytes(void);
+int cl2_comm_get_unique_id(void* out_id, size_t n_bytes);           /* error text: cl2_last_error(NULL) */
+int cl2_comm_init_rank(cl2_renderer* r, int nranks, int rank, const void* unique_id, size_t n_bytes);
+int cl2_reduce_accumulators(cl2_renderer* r);
+/* n <= 16 host doubles, in place, op 0 = sum, 1 = max over the ranks: barrier, max-over-ranks clock,
+ * whole-job ray tally, error-flag agreement before the collective */
+int cl2_comm_allreduce_f64(cl2_renderer* r, double* values, int n, int op);
+int cl2_comm_destroy(cl2_renderer* r);
+
+/* How the library organises the launches for the uploaded scene (all organisations give identical results;
+ * this is what the automatic choices of cl2_set_traversal_mode / _levels_per_launch / _pipelining came to). */
+typedef struct {
+    int32_t tree_in_lds;            /* whole tree + all triangles staged in LDS by every workgroup (<= 512 records, <= 512 triangles) */
+    int32_t persistent_subpaths;    /* subpath levels run as persistent traversal launches (+ one bounce launch per level) */
+    int32_t persistent_connections; /* connection rays run as one persistent traversal launch */
+    int32_t two_tris_per_step;      /* persistent walk tests two triangles per step (trees up to 16 MB) */
+    int32_t n_records;              /* node records (>= reference boxes: leaves above 16 triangles are split) */
+    int32_t n_lds_records;          /* records in the LDS window */
+    int32_t n_top_renumbered;       /* boxes of the top levels numbered first so that the window holds them (0 = plain visit order) */
+    int32_t lds_triangles;
+    int32_t levels_per_launch;      /* effective subpath levels per launch */
+    int32_t paths_share;            /* tuned share of the wave slots for the subpath stage, eighths (0 = not tuned yet, 9 = serial order won) */
+    int32_t pipeline_stages;        /* effective setting of cl2_set_pipelining */
+    int32_t pad;
+    int64_t tree_bytes;             /* 32 B per record + 48 B per intersection triangle */
+} cl2_organisation;
+int cl2_query_organisation(cl2_renderer* r, cl2_organisation* out);
 
 /* -- counters / profiling -- */
 int cl2_set_profiling(cl2_renderer* r, int level);  /* HIP-event timers: 0 off, 1 the connection-ray traversal launch only, 2 every stage */
@@ -146,7 +187,8 @@ int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
 /* performance-experiment switches.  Bits 0-2 make the result an INVALID render: bit 0 skips the t=1
  * light-image splat atomics, bit 1 / bit 2 skip the t >= 2 / t == 1 strategy pairs in the resolve kernel.
  * The others only change the launch organisation (same results): bits 4-6 variant of the resolve
- * kernel (2 / 4: register budget; 7: one wave per camera vertex); bits 8-10 eighths of the wave slots given to the subpath stage while the sample
+ * kernel (2 / 4: register budget; 7: one wave per camera vertex -- only in the test variant of the library,
+ * libclive2_amd_test.so, built with -DCL2_TEST_VARIANT); bits 8-10 eighths of the wave slots given to the subpath stage while the sample
  * pipeline runs on a large scene (0 = tuned); bit 12 inverts the one/two-triangles-per-step choice of
  * the persistent walk. */
 int cl2_set_debug_flags(cl2_renderer* r, int flags);
@@ -173,6 +215,11 @@ int cl2_export_aggregators(cl2_renderer* r, void* out, size_t n_records);       
  * sample_weights (K6 value only), out_camera_image (float4).  Any pointer may be NULL. */
 int cl2_export_sample_images(cl2_renderer* r, float* finalized4, float* light4, float* sample_weights,
                              float* unidirectional4, size_t n_pixels);
+/* the inverse of cl2_export_sample_images: per-sample images from host arrays (float4 / float per pixel),
+ * so that the accumulation stage (process_images, src/renderer.py:253-278) can be checked on its own
+ * against arrays produced by the reference's numpy code.  Any pointer may be NULL. */
+int cl2_import_sample_images(cl2_renderer* r, const float* finalized4, const float* light4, const float* sample_weights,
+                             const float* unidirectional4, size_t n_pixels);
 /* closest-hit probe: n rays as Ray records -> (triangle, t, u, v) per ray; exercises the traversal
  * kernel alone (src/trace.metal:144-176). */
 int cl2_probe_traverse(cl2_renderer* r, const void* rays, size_t n_rays, int32_t* best_i, float* best_t,

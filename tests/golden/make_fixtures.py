@@ -1,4 +1,5 @@
-"""Generate golden fixtures from the reference's HOST-side Python (scene/BVH/camera plumbing).
+"""Generate golden fixtures from the reference's HOST-side Python (scene/BVH/camera plumbing and
+the numpy host glue of renderer.py: light_bins, process_images, the image properties).
 
 Runs ONLY in the authoring container (needs /root/reference, which never travels to the
 GPU box).  The device code of the reference (trace.metal) cannot run anywhere in this
@@ -32,9 +33,18 @@ def _install_stand_ins():
     sys.modules["plyfile"] = ply
     mc = types.ModuleType("metalcompute")
 
+    class _Kernel:                       # dev.kernel(text).function(name): the Metal JIT, inert here
+        def function(self, name):
+            return lambda *a, **k: None
+
     class Device:
-        def buffer(self, x):
+        def buffer(self, x):             # nbytes -> zeroed buffer-protocol object; ndarray -> itself
+            if isinstance(x, (int, np.integer)):
+                return np.zeros(int(x), dtype=np.uint8)
             return x
+
+        def kernel(self, text):
+            return _Kernel()
 
     mc.Device = Device
     mc.release = lambda *_a, **_k: None
@@ -107,6 +117,58 @@ def mesh_fixture(ref_scene, ref_load, ref_bvh, ref_camera, subdiv, w, h):
                 n_boxes=np.int32(len(np_boxes)), n_triangles=np.int32(len(np_tris)))
 
 
+def renderer_glue_fixture(ref_scene, ref_renderer, w, h, seed):
+    """The numpy host glue of the reference's Renderer (renderer.py:11-13, :63, :97-111, :253-316) run on
+    seeded stand-ins for the device buffers: light-image indices with negative (unused) and >= W*H
+    (off-frame) entries, per-sample images with NaN / +-inf entries.  Inputs and outputs are
+    stored; the device kernels are never called (the fake metalcompute's functions do nothing)."""
+    rng = np.random.RandomState(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = ref_scene.create_scene_from_preset("empty", w, h)
+        r = ref_renderer.Renderer(s, kernel_path=os.path.join(REF, "trace.metal"))
+    s.__class__.__del__ = lambda self: None
+    r.__class__.__del__ = lambda self: None
+    B = w * h
+    n = ref_renderer.next_power_of_two(B * ref_renderer.MAX_PATH_LENGTH)
+    assert len(r.out_light_indices) == 4 * n
+    idx = rng.randint(-1, B + 3, size=n).astype(np.int32)
+    idx[rng.rand(n) < 0.5] = -1
+    r.out_light_indices = idx.view(np.uint8)
+    bins, offset = r.light_bins()
+    out = dict(width=np.int32(w), height=np.int32(h), n=np.int64(n), light_indices=idx,
+               summed_bins=np.asarray(bins).copy(), offset=np.asarray(offset).copy(),
+               npot_in=np.array([0, 1, 2, 3, 5, 8, 1000, 65536 * 8, 1920 * 1080 * 8], np.int64))
+    out["npot_out"] = np.array([ref_renderer.next_power_of_two(int(v)) for v in out["npot_in"]], np.int64)
+
+    def spoil(a):                        # NaN / inf entries, as broken paths produce them
+        m = rng.rand(*a.shape)
+        a[m < 0.02] = np.nan
+        a[(m >= 0.02) & (m < 0.03)] = np.inf
+        a[(m >= 0.03) & (m < 0.04)] = -np.inf
+        return a
+
+    samples = []
+    for _ in range(3):
+        fin = spoil((rng.rand(B, 4) * 2.0).astype(np.float32))
+        light = spoil((rng.rand(B, 4) * 0.5).astype(np.float32))
+        uni = spoil((rng.rand(B, 4) * 3.0).astype(np.float32))
+        cnt = np.ones(B, np.int32)
+        wts = (rng.rand(B) * 9.0).astype(np.float32)
+        wts[rng.rand(B) < 0.05] = 0.0    # zero weight mass -> 0/0 and x/0 in the final ratio
+        r.finalized_samples, r.out_light_image, r.out_camera_image = fin.view(np.uint8), light.view(np.uint8), uni.view(np.uint8)
+        r.sample_counts, r.sample_weights = cnt.view(np.uint8), wts.view(np.uint8)
+        r.process_images()
+        samples.append((fin, light, uni, cnt, wts))
+    for k, name in enumerate(("finalized", "light", "unidirectional", "counts", "weights")):
+        out["in_" + name] = np.stack([smp[k] for smp in samples])
+    out.update(summed_image=r.summed_image.copy(), summed_sample_counts=r.summed_sample_counts.copy(),
+               summed_sample_weights=r.summed_sample_weights.copy(),
+               unidirectional_image_buffer=r.unidirectional_image_buffer.copy())
+    with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+        out.update(image=r.image, unweighted_image=r.unweighted_image, unidirectional_image=r.unidirectional_image)
+    return out
+
+
 def main():
     _install_stand_ins()
     sys.path.insert(0, REF)
@@ -115,6 +177,7 @@ def main():
     import bvh as ref_bvh
     import camera as ref_camera
     import struct_types as ref_st
+    import renderer as ref_renderer
 
     sizes = {n: np.int32(getattr(ref_st, n).itemsize)
              for n in ("Ray", "Path", "Box", "Triangle", "Material", "Camera")}
@@ -138,6 +201,7 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         tm = ref_camera.tone_map(img, exposure=4.0)
     np.savez_compressed(os.path.join(OUT, "tone_map.npz"), image=img, out=tm)
+    np.savez_compressed(os.path.join(OUT, "renderer_glue.npz"), **renderer_glue_fixture(ref_scene, ref_renderer, 24, 16, 11))
     print("fixtures written to", OUT)
 
 

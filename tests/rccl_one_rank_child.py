@@ -1,8 +1,8 @@
-"""Child process of test_rccl_reduce_path_on_one_rank: a one-rank nccl (= RCCL) group on cuda:0, the
-accumulators handed to all_reduce as a device buffer and written back.  Prints `STEP <name>` lines
-so that the parent can tell where a hang happened."""
+"""Child process of test_rccl_reduce_path_on_one_rank: a one-rank RCCL communicator on device 0 created
+through the C ABI (cl2_comm_get_unique_id / cl2_comm_init_rank), the accumulators reduced in place by
+cl2_reduce_accumulators, the host-value all-reduce, teardown.  Prints `STEP <name>` lines so that the
+parent can tell where a hang happened.  torch is never imported."""
 import os
-import socket
 import sys
 
 import numpy as np
@@ -15,31 +15,34 @@ def step(name):
 
 
 def main():
-    import torch
-    import torch.distributed as dist
     from clive2_amd.renderer import Renderer, make_seeds
     from clive2_amd.scene import create_scene_from_preset
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from clive2_amd.distributed import join_communicator
     scene = create_scene_from_preset("empty", pixel_width=64, pixel_height=48)
     r = Renderer(scene, seeds=make_seeds(64 * 48))
     r.run_samples(2)
     before = r.packed_accumulators().copy()
     step("rendered")
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    step("group-up")
-    r.reduce_accumulators(always=True)
+    join_communicator(r, 0, 1)
+    step("comm-up")
+    r.reduce_accumulators()
     assert r.packed_accumulators().tobytes() == before.tobytes(), "sum over one rank changed the accumulators"
     step("handover-ok")
-    r.run_samples(1)                                  # the renderer keeps working after the hand-over
-    assert np.isfinite(r.packed_accumulators()).all()
+    assert r.allreduce_host([1.5, -2.0, 7.0], op="sum") == [1.5, -2.0, 7.0]
+    assert r.allreduce_host([1.5, -2.0], op="max") == [1.5, -2.0]
+    step("host-allreduce-ok")
+    r.run_samples(3)                                  # the renderer keeps working after the collective (pipelined samples)
+    after = r.packed_accumulators().copy()
+    assert np.isfinite(after).all() and (after.reshape(8, -1)[7] == 5).all()
     step("render-after-ok")
+    r.reduce_accumulators()
+    assert r.packed_accumulators().tobytes() == after.tobytes()
+    step("second-reduce-ok")
+    r.comm_destroy()
+    step("comm-down")
     r.close()
-    dist.destroy_process_group()
-    step("group-down")
+    step("closed")
+    print("MODULES", " ".join(sorted(m for m in sys.modules if m.split(".")[0] in ("torch",))))
 
 
 if __name__ == "__main__":

@@ -78,3 +78,71 @@ def test_movie_frames_are_split_without_overlap():
         flat = sorted(f for p in parts for f in p)
         assert flat == list(range(start, total))
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+# ---- RCCL bootstrap (id exchange only; no GPU, no RCCL, no torch) ----
+def _bootstrap_worker(rank, world, path, out_dir, delay):
+    sys.path.insert(0, ROOT)
+    import time
+    from clive2_amd.distributed import exchange_unique_id, finish_exchange
+    time.sleep(delay[rank])
+    made = []
+
+    def make_id():                       # stands in for cl2_comm_get_unique_id: only rank 0 may call it
+        made.append(1)
+        return bytes(np.random.RandomState(os.getpid() % 2 ** 31).randint(0, 256, 128, dtype=np.uint8))
+
+    uid = exchange_unique_id(rank, world, make_id, 128, path=path, timeout=30.0)
+    assert (len(made) == 1) == (rank == 0)
+    with open(os.path.join(out_dir, f"id_{rank}.bin"), "wb") as f:
+        f.write(uid)
+    # cl2_comm_init_rank would come here: it is a collective, so every rank holds the id when it returns
+    while not all(os.path.exists(os.path.join(out_dir, f"id_{r}.bin")) for r in range(world)):
+        time.sleep(0.01)
+    finish_exchange(rank, path)
+
+
+@pytest.mark.parametrize("delays", [(0.0, 0.3, 0.1), (0.4, 0.0, 0.0)])
+def test_unique_id_bootstrap_across_processes(tmp_path, delays):
+    """Rank 0 publishes the communicator id through a file (write + rename), the other ranks poll for it --
+    whichever starts first -- and every rank ends up with the same 128 bytes; rank 0 removes the file."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    path = str(tmp_path / "rdv" / "id")
+    os.makedirs(os.path.dirname(path))
+    procs = [ctx.Process(target=_bootstrap_worker, args=(r, 3, path, str(tmp_path), delays)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ids = [open(tmp_path / f"id_{r}.bin", "rb").read() for r in range(3)]
+    assert len(ids[0]) == 128 and ids[0] == ids[1] == ids[2]
+    assert not os.path.exists(path) and os.listdir(os.path.dirname(path)) == []      # nothing left behind
+
+
+def test_unique_id_bootstrap_edge_cases(tmp_path, monkeypatch):
+    from clive2_amd import distributed as d
+    # one rank: no file at all
+    assert d.exchange_unique_id(0, 1, lambda: b"x" * 128, 128, path=str(tmp_path / "none")) == b"x" * 128
+    assert not os.path.exists(tmp_path / "none")
+    # no rank 0: the others give up with an error instead of waiting for ever
+    with pytest.raises(TimeoutError):
+        d.exchange_unique_id(1, 2, None, 128, path=str(tmp_path / "never"), timeout=0.2)
+    # a file left behind by a crashed job long ago is not mistaken for this job's id
+    stale = tmp_path / "stale"
+    stale.write_bytes(b"s" * 128)
+    os.utime(stale, (1.0, 1.0))
+    with pytest.raises(TimeoutError):
+        d.exchange_unique_id(1, 2, None, 128, path=str(stale), timeout=0.2)
+    # a wrong-sized id is refused by rank 0
+    with pytest.raises(ValueError):
+        d.exchange_unique_id(0, 2, lambda: b"short", 128, path=str(tmp_path / "bad"))
+    # the default path separates launches: it depends on the port, the run id and the launcher's pid
+    monkeypatch.delenv("CLIVE2_RENDEZVOUS_FILE", raising=False)
+    monkeypatch.setenv("MASTER_PORT", "29511")
+    a = d.rendezvous_path()
+    monkeypatch.setenv("MASTER_PORT", "29512")
+    assert d.rendezvous_path() != a and str(os.getppid()) in a
+    monkeypatch.setenv("CLIVE2_RENDEZVOUS_FILE", "/tmp/explicit")
+    assert d.rendezvous_path() == "/tmp/explicit"

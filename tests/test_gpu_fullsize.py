@@ -165,3 +165,157 @@ def test_config5_instanced_interior_vs_oracle(oracle_mod):
     r2.set_traversal_mode(1)
     r2.make_light_rays(); r2.make_camera_rays(); r2.trace_light_rays(); r2.trace_camera_rays()
     assert r2.export_paths(CAMERA).tobytes() == o.out_camera_paths.tobytes()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Configs 4 and 5 at their REAL sizes: the 81,936-triangle blob and the
+# 1,003,536-triangle interior, each built once per module (native builder).  The geometry of a 16:9 scene
+# does not depend on the pixel counts (Scene.with_resolution), so one build serves the small frame that the
+# oracle can follow and the full frame of the config.
+def _mesh_scene(kind, w, h):
+    import clive2_amd as c2
+    from clive2_amd.load import get_materials
+    from clive2_amd import meshes
+    mats = get_materials()
+    mats["alpha"][5] = 0.1
+    if kind == "blob":
+        specs = [dict(mesh=meshes.noisy_blob(subdiv=6), material=5)]
+    else:
+        specs = [dict(mesh=(v, f), material=m) for v, f, m in meshes.interior_grid()]
+    return c2.create_scene(w, h, np.array([0, 1.5, 6]), np.array([0, 0, -1]), file_specs=specs, materials=mats,
+                           bvh_builder="native")
+
+
+@pytest.fixture(scope="module")
+def blob_real():
+    s = _mesh_scene("blob", 96, 54)
+    assert len(s.triangles) == 16 + 81920
+    return s
+
+
+@pytest.fixture(scope="module")
+def interior_real():
+    s = _mesh_scene("interior", 96, 54)
+    assert len(s.triangles) == 16 + 49 * 20480
+    return s
+
+
+def _exact_vs_oracle(scene, oracle_mod, samples=2):
+    """Small frame, every stage of the first sample bit-exact (Path[], aggregators), ray counts equal, then
+    more samples through run_samples: RNG state equal, image within the splat-order tolerance."""
+    from clive2_amd.renderer import Renderer, make_seeds
+    B = scene.pixel_width * scene.pixel_height
+    seeds = make_seeds(B)
+    r, o = Renderer(scene, seeds=seeds), oracle_mod.OracleRenderer(scene, seeds=seeds)
+    r.set_counting(True)
+    for x in (r, o):
+        x.make_light_rays(); x.make_camera_rays(); x.trace_light_rays(); x.trace_camera_rays()
+    for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
+        assert r.export_paths(which).tobytes() == ref.tobytes()
+    for x in (r, o):
+        x.join_paths(); x.finalize_samples(); x.gather_light_image(); x.process_images()
+    agg = r.export_aggregators()
+    assert agg["total_contribution"].tobytes() == o.weight_aggregators["total_contribution"].tobytes()
+    assert agg["weights"].tobytes() == o.weight_aggregators["weights"].tobytes()
+    assert agg["contrib_weight_sum"].tobytes() == o.weight_aggregators["contrib_weight_sum"].tobytes()
+    c = r.counters()
+    assert c["rays"] == o.rays_traced
+    # the oracle counts node / triangle tests of the reference's stack walk; the stackless walk makes the same ones
+    assert c["box_tests"] == int(o.counters["box_tests"][0]) and c["tri_tests"] == int(o.counters["tri_tests"][0])
+    r.run_samples(samples - 1)
+    for _ in range(samples - 1):
+        o.run_sample()
+    assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
+    assert r.counters()["rays"] == o.rays_traced
+    img, wts, cnt, uni = r.read_accumulators()
+    np.testing.assert_allclose(img, o.summed_image, rtol=5e-5, atol=1e-8)
+    np.testing.assert_allclose(wts, o.summed_sample_weights, rtol=5e-5, atol=1e-8)
+    assert uni.tobytes() == o.unidirectional_image_buffer.tobytes()
+    l2 = np.sqrt(((r.radiance - o.radiance) ** 2).sum(axis=2))
+    assert l2.max() < 1e-3                                   # the north star's per-pixel bound
+    return r, c
+
+
+def _full_frame_properties(scene, samples):
+    from clive2_amd.renderer import Renderer
+    W, H = scene.pixel_width, scene.pixel_height
+    r = Renderer(scene)
+    r.set_counting(True)
+    r.run_samples(samples)
+    img, wts, cnt, uni = r.read_accumulators()
+    c = r.counters()
+    assert np.isfinite(img).all() and np.isfinite(uni).all() and (cnt == samples).all()
+    assert (img >= 0).all() and img.mean() > 0 and (wts > 0).mean() > 0.99
+    per = c["rays"] / (samples * W * H)
+    assert 12 < per <= 48 and c["conn_rays"] < c["rays"]      # <= 48 rays per pixel-sample by construction (SURVEY 8d)
+    # determinism: the same seeds give the same subpaths and unidirectional estimate, bit for bit
+    r2 = Renderer(scene)
+    r2.run_samples(samples)
+    assert np.array_equal(r.get_random_buffer(), r2.get_random_buffer())
+    assert r2.read_accumulators()[3].tobytes() == uni.tobytes()
+    np.testing.assert_allclose(r2.read_accumulators()[0], img, rtol=2e-5, atol=1e-9)
+    return r, c
+
+
+def test_config4_real_size_vs_oracle(blob_real, oracle_mod):
+    """BASELINE config 4 stand-in at its stated size: 81,936 triangles / ~28k boxes.  (a) 96x54, 2 samples
+    against the oracle; (c) the organisation the library chose."""
+    r, c = _exact_vs_oracle(blob_real, oracle_mod)
+    org = r.organisation()
+    assert not org["tree_in_lds"] and org["persistent_subpaths"] and org["persistent_connections"]
+    assert org["two_tris_per_step"] == 1                      # 27,947 x 32 B + 81,936 x 48 B = 4.8 MB <= 16 MB
+    assert org["n_records"] > 20000 and org["n_lds_records"] == 512 and 0 < org["n_top_renumbered"] <= 512
+    assert 12 < c["box_tests"] / c["counted_rays"] < 22       # N_node 16.3 at 1080p (DESIGN 6)
+
+
+def test_config4_real_size_1080p_properties(blob_real):
+    """(b) the HIP path at the config's frame, 1920x1080, 2 samples."""
+    r, c = _full_frame_properties(blob_real.with_resolution(1920, 1080), 2)
+    assert r.organisation()["persistent_connections"] == 1
+    assert 14 < c["box_tests"] / c["counted_rays"] < 19 and 10 < c["tri_tests"] / c["counted_rays"] < 16
+
+
+def test_config5_real_size_vs_oracle(interior_real, oracle_mod):
+    """BASELINE config 5 stand-in at its stated size: 1,003,536 triangles / ~338k boxes (155 MB of tree: the walk
+    streams from the Infinity Cache, leaf records are packed near begin << 4 = 2^24, the top-level renumbering
+    covers 512 of 338k records)."""
+    r, c = _exact_vs_oracle(interior_real, oracle_mod)
+    org = r.organisation()
+    assert not org["tree_in_lds"] and org["persistent_subpaths"] and org["persistent_connections"]
+    assert org["two_tris_per_step"] == 0 and org["tree_bytes"] > (16 << 20)     # one triangle per step above 16 MB
+    assert org["n_records"] > 300000 and org["n_lds_records"] == 512 and 0 < org["n_top_renumbered"] <= 512
+    assert 50 < c["box_tests"] / c["counted_rays"] < 65      # N_node 57.6 at 1080p (DESIGN 6)
+    # both forms of the persistent step and the one-ray-per-lane organisation give the same subpaths
+    from clive2_amd.renderer import Renderer, make_seeds
+    seeds = make_seeds(96 * 54)
+    ref = None
+    for mode, flags in ((0, 1 << 12), (1, 0)):
+        x = Renderer(interior_real, seeds=seeds)
+        x.set_traversal_mode(mode); x.set_debug_flags(flags)
+        x.make_light_rays(); x.make_camera_rays(); x.trace_light_rays(); x.trace_camera_rays()
+        got = x.export_paths(CAMERA).tobytes() + x.export_paths(LIGHT).tobytes()
+        if mode == 0:
+            assert x.organisation()["two_tris_per_step"] == 1
+        ref = ref or got
+        assert got == ref
+        x.close()
+    r.make_light_rays()                                         # r ran 2 samples: regenerate from fresh seeds instead
+    base = Renderer(interior_real, seeds=seeds)
+    base.make_light_rays(); base.make_camera_rays(); base.trace_light_rays(); base.trace_camera_rays()
+    assert base.export_paths(CAMERA).tobytes() + base.export_paths(LIGHT).tobytes() == ref
+
+
+def test_config5_real_size_1080p_and_4k_properties(interior_real):
+    """(b) the HIP path at 1920x1080 and at the config's frame, 3840x2160 (8.3 M pixels: 26-bit pixel ids in the
+    connection tags, 36 x 8.3 M result slots), 2 and 1 samples; 48 samples at 1080p let the stage-share tuner run."""
+    r, c = _full_frame_properties(interior_real.with_resolution(1920, 1080), 2)
+    assert 50 < c["box_tests"] / c["counted_rays"] < 65 and 18 < c["tri_tests"] / c["counted_rays"] < 28
+    r.set_counting(False)
+    r.run_samples(48)                                           # >= 42: the share tuner times its candidates
+    org = r.organisation()
+    assert org["paths_share"] in (3, 4, 5, 8, 9)
+    img, wts, cnt, uni = r.read_accumulators()
+    assert (cnt == 50).all() and np.isfinite(img).all()
+    r.close()
+    r4, c4 = _full_frame_properties(interior_real.with_resolution(3840, 2160), 1)
+    assert 50 < c4["box_tests"] / c4["counted_rays"] < 65

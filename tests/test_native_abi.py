@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(native_lib):
     missing = [n for n in names if not hasattr(native_lib, n)]
     assert missing == []
     assert sorted(_native.EXPORTS) == names          # the binding knows exactly the header's surface
-    assert native_lib.cl2_abi_version() == 1
+    assert native_lib.cl2_abi_version() == 2
 
 
 def test_header_cites_the_reference_interface():
@@ -70,9 +70,43 @@ def test_renderer_fails_loudly_without_gpu():
 def test_missing_library_is_an_error(monkeypatch, tmp_path):
     from clive2_amd import _native
     monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
-    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "_libs", {})
     with pytest.raises(_native.RendererError):
         _native.lib()
+
+
+def test_editing_any_kernel_source_triggers_a_rebuild(monkeypatch, tmp_path):
+    """needs_build() looks at every file under csrc/ and at the public header (a header missing
+    from a hand-kept list left tests running against a stale library)."""
+    from clive2_amd import _native
+    _native.build()
+    assert not _native.needs_build()
+    srcs = _native._sources()
+    names = {os.path.basename(s) for s in srcs}
+    assert {"renderer_api.hip", "kernels.hpp", "connect_resolve.hpp", "connect_resolve_wide.hpp", "bvh_traverse.hpp",
+            "comm_rccl.hpp", "clive2_amd.h"} <= names
+    newest = max(os.path.getmtime(s) for s in srcs)
+    fake = tmp_path / "lib.so"
+    fake.write_bytes(b"")
+    os.utime(fake, (newest - 10, newest - 10))
+    monkeypatch.setattr(_native, "LIB_PATH", str(fake))
+    assert _native.needs_build()
+
+
+def test_product_library_has_no_torch_or_rccl_link_dependency(native_lib):
+    """The library runs on the ROCm runtime it was built for: it links libamdhip64 only; librccl is
+    opened on the first communicator call, torch never."""
+    import subprocess
+    from clive2_amd import _native
+    out = subprocess.run(["readelf", "-d", _native.LIB_PATH], capture_output=True, text=True).stdout
+    needed = re.findall(r"NEEDED.*\[(.*?)\]", out)
+    assert any("amdhip64" in n for n in needed)
+    assert not any("rccl" in n or "torch" in n or "c10" in n for n in needed), needed
+    for f in ("renderer.py", "_native.py", "render.py", "movie.py", "distributed.py"):
+        src = open(os.path.join(ROOT, "clive2_amd", f)).read()
+        body = src if f != "distributed.py" else src[:src.index("def allreduce_packed_host")]
+        assert not re.search(r"^\s*(import torch|from torch)", body, flags=re.M), f
+    assert not re.search(r"^\s*(import torch|from torch)", open(os.path.join(ROOT, "bench.py")).read(), flags=re.M)
 
 
 def test_product_path_does_not_touch_the_oracle():

@@ -1,18 +1,27 @@
 #!/bin/bash
-# Run ON THE GPU BOX from the repo root: the rocprofv3 passes and the default bench whose summaries
-# go into profiles/ (tools/profile_summaries.py turns gpurun_out/pf_* into the committed files).
-#   bash tools/profile_round.sh
+# Run ON THE GPU BOX from the repo root: the rocprofv3 passes of one bench.py workload whose summaries go into
+# profiles/ (tools/profile_summaries.py turns gpurun_out/pf_<scene>_* into profiles/<tag>_*_<scene>.*).
+#   bash tools/profile_round.sh [scene=cornell] [steps=32] [pmc_steps=4]
+# Counters are collected in their own passes, with --kernel-trace only (no other trace domain), FETCH_SIZE and
+# WRITE_SIZE apart (they do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots").
 set -e
 export TMPDIR=/tmp
+SCENE=${1:-cornell}
+STEPS=${2:-32}
+PSTEPS=${3:-4}
 OUT=gpurun_out
+B="bench.py --scene $SCENE --no-cpu-baseline --no-mesh"
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pf_stats -o runc -- python3 bench.py --no-cpu-baseline > $OUT/pf_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pf_${SCENE}_stats -o runc -- python3 $B --steps $STEPS --warmup 4 > $OUT/pf_${SCENE}_stats.log 2>&1
 echo "stats pass done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pf_fetch -o runc -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pf_fetch.log 2>&1
-echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pf_write -o runc -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pf_write.log 2>&1
-echo "write pass done"
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pf_sq -o runc -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pf_sq.log 2>&1
-echo "sq pass done"
-python bench.py > $OUT/pf_bench.log 2>&1
-tail -1 $OUT/pf_bench.log | cut -c1-200
+pass() {  # name, counters...
+    local name=$1; shift
+    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pf_${SCENE}_$name -o runc -- python3 $B --steps $PSTEPS --warmup 1 > $OUT/pf_${SCENE}_$name.log 2>&1
+    echo "$name pass done"
+}
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
+pass tcc TCC_HIT_sum TCC_MISS_sum SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU
+python bench.py --scene $SCENE --no-cpu-baseline --no-mesh --steps $STEPS --warmup 4 > $OUT/pf_${SCENE}_bench.log 2>&1
+tail -1 $OUT/pf_${SCENE}_bench.log | cut -c1-300

@@ -1,41 +1,86 @@
-"""Turn the rocprofv3 output of tools/profile_round.sh (gpurun_out/pf_*) into the files committed under
-profiles/:   python tools/profile_summaries.py r01_final"""
+"""Turn the rocprofv3 output of tools/profile_round.sh (gpurun_out/pf_<scene>_*) into the files committed under
+profiles/:   python tools/profile_summaries.py r02 cornell [width height]
+
+Writes profiles/<tag>_kernel_stats_<scene>.csv, profiles/<tag>_bench_<scene>.log and profiles/<tag>_pmc_<scene>.json.
+The JSON holds, per kernel and per launch: FETCH_SIZE / WRITE_SIZE (KiB as reported, separate passes), the HBM
+bytes after the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts 64 B per 128-B request on wide
+coalesced reads: hbm_bytes = (2*FETCH + WRITE) * 1024), the SQ counters, TCC hits / misses, and the hash of the
+kernel sources that were profiled -- bench.py quotes these figures (marked "static") only while that hash still
+matches the sources it runs."""
 import collections
 import csv
 import glob
 import json
+import os
+import re
 import shutil
-import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def short(name):
+    """cl2::k_traverse_persistent<false, true, cl2::ConnRaySource>(...) -> k_traverse_persistent<false,true,ConnRaySource>"""
+    n = name.split("(")[0].replace("void ", "").replace("cl2::", "").replace(" ", "")
+    return n
+
+
+def per_launch(pattern):
+    files = glob.glob(pattern, recursive=True)
+    if not files:
+        return {}
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for r in csv.DictReader(open(files[0])):
+        a = agg[short(r["Kernel_Name"])][r["Counter_Name"]]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return {k: {c: (v / n, n) for c, (n, v) in cs.items()} for k, cs in agg.items()}
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
-    shutil.copy(glob.glob("gpurun_out/pf_stats/**/*_kernel_stats.csv", recursive=True)[0], f"profiles/{tag}_kernel_stats.csv")
-    shutil.copy("gpurun_out/pf_bench.log", f"profiles/{tag}_bench.log")
-    out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline`; "
-                   "units KiB per launch as reported; gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads "
-                   "(MI355X_MICROARCH.md HBM section) -> hbm_bytes_per_launch = (2*FETCH + WRITE)*1024"}
-    per = {}
-    for kind in ("fetch", "write"):
-        f = glob.glob(f"gpurun_out/pf_{kind}/**/*_counter_collection.csv", recursive=True)[0]
-        agg = collections.defaultdict(lambda: [0, 0.0])
-        for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            agg[k][0] += 1
-            agg[k][1] += float(r["Counter_Value"])
-        out[kind.upper() + "_SIZE_KiB"] = {k: {"launches": n, "per_launch": round(v / n, 1)} for k, (n, v) in agg.items()}
-        for k, (n, v) in agg.items():
-            per.setdefault(k, {})[kind] = v / n
-    out["hbm_bytes_per_launch"] = {k: round((2 * v.get("fetch", 0) + v.get("write", 0)) * 1024) for k, v in per.items() if "rocclr" not in k}
-    json.dump(out, open(f"profiles/{tag}_pmc_hbm.json", "w"), indent=1)
-    sq = subprocess.run([sys.executable, "tools/pmc_summary.py", "gpurun_out/pf_sq"], capture_output=True, text=True).stdout
-    open(f"profiles/{tag}_pmc_sq.txt", "w").write(sq)
-    for r in csv.DictReader(open(f"profiles/{tag}_kernel_stats.csv")):
-        if float(r["Percentage"]) > 1:
-            print(f'{r["Name"][:60]:60s} calls={r["Calls"]:>5s} avg_us={float(r["AverageNs"]) / 1e3:10.1f} pct={r["Percentage"]}')
-    for k, v in sorted(out["hbm_bytes_per_launch"].items(), key=lambda kv: -kv[1])[:8]:
-        print(f"{k:56s} {v / 1e6:10.1f} MB per launch")
+    tag, scene = sys.argv[1], sys.argv[2]
+    W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1920, 1080)
+    import bench
+    base = f"gpurun_out/pf_{scene}"
+    stats = glob.glob(f"{base}_stats/**/*_kernel_stats.csv", recursive=True)
+    if stats:
+        shutil.copy(stats[0], f"profiles/{tag}_kernel_stats_{scene}.csv")
+    if os.path.exists(f"{base}_bench.log"):
+        shutil.copy(f"{base}_bench.log", f"profiles/{tag}_bench_{scene}.log")
+    kernels = collections.defaultdict(dict)
+    for kind in ("fetch", "write", "sq", "tcc"):
+        for k, cs in per_launch(f"{base}_{kind}/**/*_counter_collection.csv").items():
+            if "rocclr" in k or "export" in k:
+                continue
+            for c, (v, n) in cs.items():
+                kernels[k][c] = round(v, 1)
+                kernels[k]["launches_" + kind] = n
+    for k, row in kernels.items():
+        if "FETCH_SIZE" in row and "WRITE_SIZE" in row:
+            row["hbm_bytes"] = round((2 * row["FETCH_SIZE"] + row["WRITE_SIZE"]) * 1024)
+        if "TCC_HIT_sum" in row and "TCC_MISS_sum" in row and row["TCC_HIT_sum"] + row["TCC_MISS_sum"] > 0:
+            row["l2_hit_rate"] = round(row["TCC_HIT_sum"] / (row["TCC_HIT_sum"] + row["TCC_MISS_sum"]), 4)
+        if row.get("SQ_WAVE_CYCLES"):
+            row["wait_share"] = round(row.get("SQ_WAIT_ANY", 0.0) / row["SQ_WAVE_CYCLES"], 4)
+        # average active lanes per VALU wave-instruction: thread-cycles / (4 cycles per quad-cycle-counted instruction)
+        if row.get("SQ_THREAD_CYCLES_VALU") and row.get("SQ_INSTS_VALU"):
+            row["thread_cycles_per_valu_inst"] = round(row["SQ_THREAD_CYCLES_VALU"] / row["SQ_INSTS_VALU"], 2)
+    conn = [k for k in kernels if (k.startswith("k_traverse_conn<false") or
+                                   (k.startswith("k_traverse_persistent<false") and "ConnRaySource" in k))]
+    out = {"note": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*, TCC_* each in its own run, --kernel-trace only) of "
+                   f"`python3 bench.py --scene {scene} --no-cpu-baseline --no-mesh --steps 4 --warmup 1`; values are averages per launch; "
+                   "FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count, "
+                   "MI355X_MICROARCH.md HBM section); SQ_WAVE_CYCLES/SQ_WAIT_*/SQ_ACTIVE_INST_* are quad-cycles",
+           "scene": scene, "width": W, "height": H, "sources_sha": bench.kernel_sources_sha(),
+           "conn_traversal_kernel": conn[0] if conn else None, "kernels": kernels}
+    json.dump(out, open(f"profiles/{tag}_pmc_{scene}.json", "w"), indent=1, sort_keys=True)
+    if stats:
+        for r in csv.DictReader(open(f"profiles/{tag}_kernel_stats_{scene}.csv")):
+            if float(r["Percentage"]) > 1:
+                print(f'{r["Name"][:70]:70s} calls={r["Calls"]:>5s} avg_us={float(r["AverageNs"]) / 1e3:10.1f} pct={r["Percentage"]}')
+    for k, row in sorted(kernels.items(), key=lambda kv: -kv[1].get("hbm_bytes", 0))[:8]:
+        print(f"{k[:60]:60s} hbm {row.get('hbm_bytes', 0) / 1e6:9.1f} MB  VALU {row.get('SQ_INSTS_VALU', 0):.3g}  wait {row.get('wait_share')}  L2 hit {row.get('l2_hit_rate')}")
 
 
 if __name__ == "__main__":
