@@ -164,6 +164,23 @@ __device__ __forceinline__ Hit closest_hit(const BvhLds& s, const BvhView& b, V3
 // of node visits, triangle tests and comparisons of each ray is exactly that of closest_hit_impl.
 namespace cl2 {
 
+// ray_triangle_intersect, trace.metal:117-142, against a pre-fetched record {v0, e1, e2}; keeps the hit on strict t < best.t
+__device__ __forceinline__ void tri_test(V3 o, V3 d, float4 a0, float4 a1, float4 a2, int index, Hit& best) {
+    const V3 e1 = v3(a1), e2 = v3(a2);
+    const V3 h = cross(d, e2);
+    const float f = rcp_exact(dot(e1, h));
+    const V3 sv = o - v3(a0);
+    const float u = f * dot(sv, h);
+    if (!(u < 0 || u > 1)) {
+        const V3 q = cross(sv, e1);
+        const float v = f * dot(d, q);
+        if (!(v < 0 || u + v > 1)) {
+            const float t = f * dot(e2, q);
+            if (t > DELTA_F && t < best.t) { best.tri = index; best.t = t; best.u = u; best.v = v; }
+        }
+    }
+}
+
 constexpr int RAY_CHUNK_MAX = 512;  // rays handed to a wave per global atomic: 64..512, about a quarter of a wave's fair share
 
 template <bool COUNT, bool TWO_TRIS, class Source>

@@ -270,6 +270,96 @@ struct ShadeLds {
     MaterialDev mats[LDS_MAT_CAP];
 };
 
+// Where the shading records of a launch live: LDS copies for small scenes, else global memory.
+struct ShadeSrc {
+    const ShadeLds* lds; bool shade_lds, mats_lds;
+    const float4* tri_shade_g; const MaterialDev* mats_g;
+};
+
+// One iteration of the path loop AFTER the closest hit is known (trace.metal:417-516): shading normal,
+// side of the surface, microfacet normal, the bounce, throughput.  In: the current vertex's outgoing ray
+// (ro, rd), its throughput colour and total importance, the carried forward pdf `fwd`, the RNG state.
+// Out (go_on): the next vertex (the reference's new_ray) complete but for its own reverse pdf, the reverse pdf
+// of the CURRENT vertex (`rev`: l_importance of a camera vertex, c_importance of a light vertex, :501/:505)
+// and the forward pdf the next iteration carries.  `from_camera` is a compile-time constant in the
+// per-level kernels and a per-lane value in the persistent whole-subpath kernel; the arithmetic is the same.
+struct BounceOut {
+    bool go_on;
+    V3 o, d, n, col;
+    float tot, next_fwd, rev;
+    int meta, tri;
+};
+__device__ __forceinline__ BounceOut shade_and_bounce(bool from_camera, const Hit& hh, V3 ro, V3 rd, V3 rcol, float r_tot,
+                                                      float fwd, uint2& sd, bool& seeds_dirty, const ShadeSrc& src) {
+    BounceOut out;
+    out.go_on = false;
+    out.o = ro; out.d = rd; out.n = ro; out.col = rcol;
+    out.tot = 0.0f; out.next_fwd = 0.0f; out.rev = 0.0f; out.meta = 0; out.tri = -1;
+    const int best_i = hh.tri;
+    if (best_i == -1) return out;
+    const float best_t = hh.t, u = hh.u, v = hh.v;
+    float4 s0, s1, s2, s3;
+    if (src.shade_lds) { s0 = src.lds->tri_shade[4 * best_i]; s1 = src.lds->tri_shade[4 * best_i + 1]; s2 = src.lds->tri_shade[4 * best_i + 2]; s3 = src.lds->tri_shade[4 * best_i + 3]; }
+    else { s0 = src.tri_shade_g[4 * best_i]; s1 = src.tri_shade_g[4 * best_i + 1]; s2 = src.tri_shade_g[4 * best_i + 2]; s3 = src.tri_shade_g[4 * best_i + 3]; }
+    const int material = __float_as_int(s0.w);
+    const bool is_light = __float_as_int(s1.w) != 0, is_camera = __float_as_int(s2.w) != 0;
+    const MaterialDev mat = src.mats_lds ? src.lds->mats[material] : src.mats_g[material];
+    const int mtype = __float_as_int(mat.color_type.w);
+    const float alpha = mat.emission_alpha.w;
+    const V3 tn = v3(s3);
+
+    const V3 sn = normalize((v3(s0) * (1 - u - v) + v3(s1) * u) + v3(s2) * v);   // sample_normal :330-332
+    const float facing = dot(-rd, tn);
+    V3 nrm = sn;
+    float ni = 1.0f, no = mat.ior;
+    if (facing > 0) { }
+    else if (facing < 0) { nrm = -sn; ni = mat.ior; no = 1.0f; }
+    else return out;                                                           // :433-435
+    const bool hit_light = is_light && dot(rd, tn) < 0.0f;
+    const V3 wi = -rd;
+    const float rxa = xorshift_random(sd.x);
+    const float rya = xorshift_random(sd.y);
+    const float rxb = xorshift_random(sd.x);
+    const float ryb = xorshift_random(sd.y);
+    seeds_dirty = true;
+
+    // Microfacet normal (:466).  For a smooth Lambertian surface (alpha == 0, type 0) GGX_sample
+    // reduces exactly to normalize(n): phi = atan(0) = 0, so m = normalize(0*x + 0*y + 1*n), and m
+    // only feeds the two sign tests below, which ignore the sign of a zero component.  The draw
+    // ry == 1 (0/0 -> NaN) keeps the general route.
+    V3 m;
+    if (mtype == 0 && alpha == 0.0f && rya != 1.0f) m = normalize(nrm);
+    else m = GGX_sample(nrm, rxa, rya, alpha);
+    if (dot(wi, m) < 0.0f || dot(m, nrm) < 0.0f) return out;
+    float fresnel = 0.0f;                                  // only types 1 and 2 read it (:476-485)
+    if (mtype != 0) fresnel = degreve_fresnel(wi, m, ni, no);
+    Bounce b;
+    if (mtype == 0) b = diffuse_bounce(wi, nrm, from_camera, rxb, ryb);
+    else if (mtype == 1) {
+        if (rxb <= fresnel) b = reflect_bounce(wi, nrm, m, ni, no, alpha, from_camera);
+        else b = transmit_bounce(wi, nrm, m, ni, no, alpha, from_camera);
+    } else if (mtype == 2) {
+        if (rxb <= fresnel) b = reflect_bounce(wi, nrm, m, ni, no, alpha, from_camera);
+        else b = diffuse_bounce(wi, nrm, from_camera, rxb, ryb);
+    } else b = reflect_bounce(wi, nrm, m, ni, no, alpha, from_camera);
+
+    const float wi_n = dot(wi, tn), wo_n = dot(b.wo, tn);
+    V3 ncol = b.f * rcol;
+    if ((wi_n > 0.0f && wo_n > 0.0f) || (wi_n < 0.0f && wo_n > 0.0f)) ncol = ncol * v3(mat.color_type);
+
+    if (b.f == 0.0f) return out;                           // :509
+    out.rev = from_camera ? b.l_p : b.c_p;                 // :501 / :505
+    // new_ray (:437-449, :496-506) becomes the current vertex of the next level
+    out.o = ro + rd * best_t;
+    out.d = b.wo; out.n = nrm; out.col = ncol;
+    out.tot = r_tot * fwd;                                 // :502 / :506
+    out.meta = material | (hit_light ? META_HIT_LIGHT : 0) | (is_camera ? META_HIT_CAMERA : 0);
+    out.tri = best_i;
+    out.next_fwd = from_camera ? b.c_p : b.l_p;            // next_ray, :500 / :504
+    out.go_on = true;
+    return out;
+}
+
 template <bool FROM_CAMERA, bool COUNT, bool EXT_HIT>
 __global__ __launch_bounds__(BLOCK, 6) void k_trace_subpath(
         BvhView bvh, Stats* stats, int first, int end, const int* __restrict__ queue_in,
@@ -286,6 +376,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_trace_subpath(
     if (mats_lds) for (int i = threadIdx.x; i < n_mats; i += BLOCK) sh.mats[i] = mats_g[i];
     if (!EXT_HIT) stage_bvh(lds, bvh);                     // ends with the barrier
     else __syncthreads();
+    const ShadeSrc shade_src{&sh, shade_lds, mats_lds, tri_shade_g, mats_g};
 
     const unsigned n = *count_in;
     const unsigned j = blockIdx.x * BLOCK + threadIdx.x;
@@ -311,10 +402,8 @@ __global__ __launch_bounds__(BLOCK, 6) void k_trace_subpath(
 
     for (int level = first; level < end; level++) {
         if (!__any(alive)) break;
-        bool go_on = false;
-        V3 n_o = ro, n_d = rd, n_n = rn, n_col = rcol;
-        float n_tot = 0.0f, next_fwd = 0.0f;
-        int n_meta = 0, n_tri = -1;
+        BounceOut bo;
+        bo.go_on = false;
         if (alive) {
             Hit hh;
             if (EXT_HIT) {
@@ -324,95 +413,31 @@ __global__ __launch_bounds__(BLOCK, 6) void k_trace_subpath(
                 nrays++;
                 hh = closest_hit<COUNT>(lds, bvh, ro, rd, rcp3(rd), nb, nt);             // :409-415
             }
-            const int best_i = hh.tri;
-            if (best_i != -1) {
-                const float best_t = hh.t, u = hh.u, v = hh.v;
-                float4 s0, s1, s2, s3;
-                if (shade_lds) { s0 = sh.tri_shade[4 * best_i]; s1 = sh.tri_shade[4 * best_i + 1]; s2 = sh.tri_shade[4 * best_i + 2]; s3 = sh.tri_shade[4 * best_i + 3]; }
-                else { s0 = tri_shade_g[4 * best_i]; s1 = tri_shade_g[4 * best_i + 1]; s2 = tri_shade_g[4 * best_i + 2]; s3 = tri_shade_g[4 * best_i + 3]; }
-                const int material = __float_as_int(s0.w);
-                const bool is_light = __float_as_int(s1.w) != 0, is_camera = __float_as_int(s2.w) != 0;
-                const MaterialDev mat = mats_lds ? sh.mats[material] : mats_g[material];
-                const int mtype = __float_as_int(mat.color_type.w);
-                const float alpha = mat.emission_alpha.w;
-                const V3 tn = v3(s3);
-
-                const V3 sn = normalize((v3(s0) * (1 - u - v) + v3(s1) * u) + v3(s2) * v);   // sample_normal :330-332
-                const float facing = dot(-rd, tn);
-                V3 nrm = sn;
-                float ni = 1.0f, no = mat.ior;
-                bool ok = true;
-                if (facing > 0) { }
-                else if (facing < 0) { nrm = -sn; ni = mat.ior; no = 1.0f; }
-                else ok = false;                                                           // :433-435
-                if (ok) {
-                    const bool hit_light = is_light && dot(rd, tn) < 0.0f;
-                    const V3 wi = -rd;
-                    const float rxa = xorshift_random(sd.x);
-                    const float rya = xorshift_random(sd.y);
-                    const float rxb = xorshift_random(sd.x);
-                    const float ryb = xorshift_random(sd.y);
-                    seeds_dirty = true;
-
-                    // Microfacet normal (:466).  For a smooth Lambertian surface (alpha == 0, type 0) GGX_sample
-                    // reduces exactly to normalize(n): phi = atan(0) = 0, so m = normalize(0*x + 0*y + 1*n), and m
-                    // only feeds the two sign tests below, which ignore the sign of a zero component.  The draw
-                    // ry == 1 (0/0 -> NaN) keeps the general route.
-                    V3 m;
-                    if (mtype == 0 && alpha == 0.0f && rya != 1.0f) m = normalize(nrm);
-                    else m = GGX_sample(nrm, rxa, rya, alpha);
-                    if (!(dot(wi, m) < 0.0f) && !(dot(m, nrm) < 0.0f)) {
-                        float fresnel = 0.0f;                                  // only types 1 and 2 read it (:476-485)
-                        if (mtype != 0) fresnel = degreve_fresnel(wi, m, ni, no);
-                        Bounce b;
-                        if (mtype == 0) b = diffuse_bounce(wi, nrm, FROM_CAMERA, rxb, ryb);
-                        else if (mtype == 1) {
-                            if (rxb <= fresnel) b = reflect_bounce(wi, nrm, m, ni, no, alpha, FROM_CAMERA);
-                            else b = transmit_bounce(wi, nrm, m, ni, no, alpha, FROM_CAMERA);
-                        } else if (mtype == 2) {
-                            if (rxb <= fresnel) b = reflect_bounce(wi, nrm, m, ni, no, alpha, FROM_CAMERA);
-                            else b = diffuse_bounce(wi, nrm, FROM_CAMERA, rxb, ryb);
-                        } else b = reflect_bounce(wi, nrm, m, ni, no, alpha, FROM_CAMERA);
-
-                        const float wi_n = dot(wi, tn), wo_n = dot(b.wo, tn);
-                        V3 ncol = b.f * rcol;
-                        if ((wi_n > 0.0f && wo_n > 0.0f) || (wi_n < 0.0f && wo_n > 0.0f)) ncol = ncol * v3(mat.color_type);
-
-                        if (!(b.f == 0.0f)) {                       // :509
-                            // path.rays[level] = ray, its reverse pdf now known (:501 / :505, :512)
-                            if (FROM_CAMERA) r_l = b.l_p; else r_c = b.c_p;
-                            const size_t cur = (size_t)level * B + pid;
-                            if (level == first) {
-                                if (FROM_CAMERA) pb.P1[cur] = f4(rd, r_l); else pb.P0[cur] = f4(ro, r_c);
-                            } else {
-                                pb.P0[cur] = f4(ro, r_c);
-                                pb.P1[cur] = f4(rd, r_l);
-                                pb.P2[cur] = f4(rn, __int_as_float(r_meta));
-                                pb.P3[cur] = f4(rcol, r_tot);
-                                pb.tri[cur] = r_tri;
-                            }
-                            stored = level;
-                            // new_ray (:437-449, :496-506) becomes the current vertex of the next level
-                            n_o = ro + rd * best_t;
-                            n_d = b.wo; n_n = nrm; n_col = ncol;
-                            n_tot = r_tot * fwd;                    // :502 / :506
-                            n_meta = material | (hit_light ? META_HIT_LIGHT : 0) | (is_camera ? META_HIT_CAMERA : 0);
-                            n_tri = best_i;
-                            next_fwd = FROM_CAMERA ? b.c_p : b.l_p; // next_ray, :500 / :504
-                            go_on = true;
-                        }
-                    }
+            bo = shade_and_bounce(FROM_CAMERA, hh, ro, rd, rcol, r_tot, fwd, sd, seeds_dirty, shade_src);
+            if (bo.go_on) {
+                // path.rays[level] = ray, its reverse pdf now known (:501 / :505, :512)
+                if (FROM_CAMERA) r_l = bo.rev; else r_c = bo.rev;
+                const size_t cur = (size_t)level * B + pid;
+                if (level == first) {
+                    if (FROM_CAMERA) pb.P1[cur] = f4(rd, r_l); else pb.P0[cur] = f4(ro, r_c);
+                } else {
+                    pb.P0[cur] = f4(ro, r_c);
+                    pb.P1[cur] = f4(rd, r_l);
+                    pb.P2[cur] = f4(rn, __int_as_float(r_meta));
+                    pb.P3[cur] = f4(rcol, r_tot);
+                    pb.tri[cur] = r_tri;
                 }
+                stored = level;
             }
         }
-        if (go_on) {
-            ro = n_o; rd = n_d; rn = n_n; rcol = n_col;
+        if (bo.go_on) {
+            ro = bo.o; rd = bo.d; rn = bo.n; rcol = bo.col;
             r_c = FROM_CAMERA ? fwd : 0.0f;
             r_l = FROM_CAMERA ? 0.0f : fwd;
-            r_tot = n_tot; r_meta = n_meta; r_tri = n_tri;
-            fwd = next_fwd;
+            r_tot = bo.tot; r_meta = bo.meta; r_tri = bo.tri;
+            fwd = bo.next_fwd;
         }
-        alive = go_on;
+        alive = bo.go_on;
     }
 
     if (stored >= 0) pb.len[pid] = stored + 1;
@@ -447,6 +472,203 @@ __global__ __launch_bounds__(BLOCK, 6) void k_trace_subpath(
     if (end >= MAX_VERTS) return;                          // uniform: no queue after the final bounce
     const unsigned idx = block_compact_index(hand_over, count_out);
     if (hand_over) queue_out[idx] = pid;
+}
+
+// ---------------------------------------------------------------- K3 for large trees: whole subpaths, persistent
+// Both subpaths of a pixel -- light first, then camera: the camera walk continues the pixel's RNG stream where
+// the light walk left it (one seed pair per pixel, renderer.py:86-87, used in that order by run_sample) -- walked
+// by ONE lane of a persistent launch.  A lane is a small state machine:
+//     TRAV  one node visit / triangle test per step, exactly the steps of traverse_persistent
+//     PEND  closest hit known, waiting for the wave's next bounce phase
+//     IDLE  takes the next pixel of the launch (chunks handed to waves by one global atomic)
+// The bounce (shade_and_bounce: ~10x the instructions of a step, divergent by material) is not run for the
+// one or two lanes that finish in a step but for all lanes that have gathered in PEND, when there are
+// `bounce_lanes` of them, when the oldest has waited `bounce_wait` steps, or when no lane is left walking.
+// Between bounces the walking state lives where the per-level launches keep it: the current vertex is stored
+// complete but for its reverse pdf when it is created and patched when the next bounce is known, so a lane
+// carries only the ray, the pixel, the level, the RNG state and the forward pdf across its traversal steps.
+//
+// Against one traversal launch + one bounce launch per level and subpath kind (24 launches per sample, each
+// ending in a tail of a few long rays, about half of their time on a 2 M-ray level) this is one launch per
+// sample with one tail.  Same arithmetic on the same operands in the same order per path: identical results.
+enum { LANE_IDLE = 0, LANE_TRAV = 1, LANE_PEND = 2 };
+
+template <bool COUNT, bool TWO_TRIS, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
+        BvhView bvh, int B, unsigned* __restrict__ work_counter, PathBufs lp, PathBufs cp, uint2* __restrict__ seeds,
+        const float4* __restrict__ tri_shade_g, const MaterialDev* __restrict__ mats_g, int n_mats, Stats* stats,
+        int bounce_lanes, int bounce_wait, int kinds /* 1 light subpaths only, 2 camera only, 3 both (light first) */) {
+    BvhLds s{nullptr, nullptr};
+    stage_bvh(s, bvh);                                     // ends with the barrier
+    const BvhView& b = bvh;
+    // shading records and the (tiny) material table are read through the caches: this launch is for trees
+    // that do not fit LDS, whose shading triangles do not either
+    const ShadeSrc src{nullptr, false, false, tri_shade_g, mats_g};
+    const int lane = threadIdx.x & 63;
+    const unsigned n = (unsigned)B;
+    const unsigned waves = gridDim.x * (blockDim.x >> 6);
+    unsigned chunk = n / (waves * 4u);
+    chunk = chunk < 64u ? 64u : (chunk > (unsigned)RAY_CHUNK_MAX ? (unsigned)RAY_CHUNK_MAX : chunk);
+    unsigned w_next = 0, w_end = 0;
+    bool dry = false;
+    int waited = 0;                                        // wave-uniform: steps since a lane first went PEND
+
+    // per-lane state
+    int state = LANE_IDLE, pid = 0, level = 0, plen = 0;
+    bool cam = false, fast = true, seeds_dirty = false;
+    uint2 sd = make_uint2(0, 0);
+    float fwd = 0.0f;
+    V3 o = v3(0, 0, 0), d = o, inv = o;
+    Hit best{-1, __builtin_inff(), 0.0f, 0.0f};
+    const int n_nodes = b.n_nodes;
+    int node = n_nodes, tri_i = 0, tri_end = 0;
+    unsigned n_box = 0, n_tri = 0, n_rays = 0;
+
+    // (re)start the walk of the current subpath at vertex `level` (its outgoing ray was stored with the vertex)
+    auto start_ray = [&](V3 ro, V3 rd) {
+        o = ro; d = rd;
+        inv = rcp3(d);
+        fast = finite3(inv);
+        best = Hit{-1, __builtin_inff(), 0.0f, 0.0f};
+        node = 0; tri_i = 0; tri_end = 0;
+        state = LANE_TRAV;
+        n_rays++;
+    };
+
+    while (true) {
+        // ---- idle lanes take the next pixels of the launch ----
+        unsigned long long idle = __ballot(state == LANE_IDLE);
+        while (idle && !dry) {
+            if (w_next >= w_end) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(work_counter, chunk);
+                base = __shfl(base, 0);
+                if (base >= n) { dry = true; break; }
+                w_next = base;
+                w_end = base + chunk < n ? base + chunk : n;
+            }
+            const unsigned avail = w_end - w_next;
+            const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
+            if (state == LANE_IDLE && rank < avail) {
+                pid = (int)(w_next + rank);
+                cam = !(kinds & 1); level = 0; plen = 0; seeds_dirty = false;
+                sd = seeds[pid];
+                fwd = cam ? cp.carry[pid] : lp.carry[pid];
+                if (cam) start_ray(v3(cp.P0[pid]), v3(cp.P1[pid])); else start_ray(v3(lp.P0[pid]), v3(lp.P1[pid]));
+            }
+            const unsigned taken = __popcll(idle) < avail ? __popcll(idle) : avail;
+            w_next += taken;
+            idle = __ballot(state == LANE_IDLE);
+        }
+        const unsigned long long pend = __ballot(state == LANE_PEND), trav = __ballot(state == LANE_TRAV);
+        if (!pend && !trav) break;
+
+        // ---- bounce phase for the lanes that have gathered ----
+        waited = pend ? waited + 1 : 0;
+        if (pend && (__popcll(pend) >= bounce_lanes || waited > bounce_wait || !trav)) {
+            waited = 0;
+            if (state == LANE_PEND) {
+                PathBufs& pb = cam ? cp : lp;
+                const size_t cur = (size_t)level * B + pid;
+                bool go_on = false;
+                if (best.tri != -1) {
+                    const float4 p3 = pb.P3[cur];
+                    const BounceOut bo = shade_and_bounce(cam, best, o, d, v3(p3), p3.w, fwd, sd, seeds_dirty, src);
+                    if (bo.go_on) {
+                        // the current vertex is complete now: patch its reverse pdf (:501 / :505, :512)
+                        if (cam) pb.P1[cur] = f4(d, bo.rev); else pb.P0[cur] = f4(o, bo.rev);
+                        plen = level + 1;
+                        if (level + 1 < MAX_VERTS) {
+                            // the next vertex, complete but for its own reverse pdf; its forward pdf is the one carried here
+                            const size_t nxt = cur + B;
+                            pb.P0[nxt] = f4(bo.o, cam ? fwd : 0.0f);
+                            pb.P1[nxt] = f4(bo.d, cam ? 0.0f : fwd);
+                            pb.P2[nxt] = f4(bo.n, __int_as_float(bo.meta));
+                            pb.P3[nxt] = f4(bo.col, bo.tot);
+                            pb.tri[nxt] = bo.tri;
+                            fwd = bo.next_fwd;
+                            level++;
+                            start_ray(bo.o, bo.d);
+                            go_on = true;
+                        }
+                    }
+                }
+                if (!go_on) {
+                    // this subpath is complete
+                    pb.len[pid] = plen;
+                    if (!cam && (kinds & 2)) {
+                        cam = true; level = 0; plen = 0;
+                        fwd = cp.carry[pid];
+                        start_ray(v3(cp.P0[pid]), v3(cp.P1[pid]));
+                    } else {
+                        if (seeds_dirty) seeds[pid] = sd;
+                        state = LANE_IDLE;
+                    }
+                }
+            }
+            continue;                                      // refill the lanes that went idle before the next step
+        }
+
+        // ---- one traversal step per walking lane (the step of traverse_persistent) ----
+        const bool all_fast = __all(state != LANE_TRAV || fast);
+        if (state == LANE_TRAV) {
+            if (tri_i >= tri_end && node < n_nodes) {
+                float4 lo, hi;
+                if (node < b.n_lds_nodes) { lo = s.nodes[2 * node]; hi = s.nodes[2 * node + 1]; }
+                else { lo = b.nodes[2 * node]; hi = b.nodes[2 * node + 1]; }
+                const int next = __float_as_int(lo.w);
+                if (COUNT) n_box++;
+                const float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
+                const float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
+                float tmin, tmax;
+                if (all_fast) {
+                    tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                                           __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
+                    tmax = __builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
+                } else {
+                    tmin = max_msl(max_msl(min_msl(t0x, t1x), min_msl(t0y, t1y)), max_msl(min_msl(t0z, t1z), 0.0f));
+                    tmax = min_msl(min_msl(max_msl(t0x, t1x), max_msl(t0y, t1y)), min_msl(max_msl(t0z, t1z), __builtin_inff()));
+                }
+                node = next;
+                if (tmin <= tmax && tmin < best.t) {
+                    const int info = __float_as_int(hi.w);
+                    if (info < 0) node = ~info;
+                    else { tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
+                }
+            }
+            if (tri_i < tri_end) {
+                const int i0 = tri_i;
+                const bool two = TWO_TRIS && i0 + 1 < tri_end;
+                const int i1 = two ? i0 + 1 : i0;
+                tri_i = i1 + 1;
+                float4 a0, a1, a2, c0, c1, c2;
+                if (b.lds_tris) {
+                    a0 = s.tris[3 * i0]; a1 = s.tris[3 * i0 + 1]; a2 = s.tris[3 * i0 + 2];
+                    if (TWO_TRIS) { c0 = s.tris[3 * i1]; c1 = s.tris[3 * i1 + 1]; c2 = s.tris[3 * i1 + 2]; }
+                } else {
+                    a0 = b.tris[3 * i0]; a1 = b.tris[3 * i0 + 1]; a2 = b.tris[3 * i0 + 2];
+                    if (TWO_TRIS) { c0 = b.tris[3 * i1]; c1 = b.tris[3 * i1 + 1]; c2 = b.tris[3 * i1 + 2]; }
+                }
+                if (COUNT) n_tri += two ? 2 : 1;
+                tri_test(o, d, a0, a1, a2, i0, best);
+                if (TWO_TRIS && two) tri_test(o, d, c0, c1, c2, i1, best);
+            }
+            if (tri_i >= tri_end && node >= n_nodes) state = LANE_PEND;
+        }
+    }
+
+    for (int off = 32; off > 0; off >>= 1) {
+        n_rays += __shfl_down(n_rays, off);
+        if (COUNT) { n_box += __shfl_down(n_box, off); n_tri += __shfl_down(n_tri, off); }
+    }
+    if (lane == 0) {
+        atomicAdd(&stats->rays, (unsigned long long)n_rays);
+        if (COUNT) {
+            atomicAdd(&stats->box_tests, (unsigned long long)n_box);
+            atomicAdd(&stats->tri_tests, (unsigned long long)n_tri);
+            atomicAdd(&stats->counted_rays, (unsigned long long)n_rays);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- connection stage

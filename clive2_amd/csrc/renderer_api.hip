@@ -205,11 +205,21 @@ inline size_t bvh_lds_bytes(const cl2_renderer* r) {
 inline bool tree_in_lds(const cl2_renderer* r) { return r->bvh.lds_tris && r->bvh.n_nodes <= r->bvh.n_lds_nodes; }
 inline bool split_paths(const cl2_renderer* r) {
     if (r->traversal_mode == 1 || r->traversal_mode == 3) return false;
-    if (r->traversal_mode == 2) return true;
+    if (r->traversal_mode == 2 || r->traversal_mode == 4) return true;
     return !tree_in_lds(r);
 }
 inline bool split_conn(const cl2_renderer* r) {
-    return r->traversal_mode == 2 || r->traversal_mode == 3 || (r->traversal_mode == 0 && !tree_in_lds(r));
+    return r->traversal_mode >= 2 || (r->traversal_mode == 0 && !tree_in_lds(r));
+}
+// Whole subpaths (light, then camera, all levels) in ONE persistent launch per sample (k_subpaths_persistent)
+// instead of a traversal + a bounce launch per level and kind: mode 4.  Measured at 1080p (ms per sample, serial order /
+// sample pipeline): glass 15.9 / 12.6 per level, 13.0 / 13.6 whole; interior 36.2 / 32.7 per level, 33.5 / 34.1 whole.
+// One launch has one tail instead of 24, which is what the serial order pays for; the sample pipeline already fills
+// those tails with the other stage's work, and there the whole-subpath launch loses to its own costs (5 instead of 8
+// waves per SIMD for the bounce code's registers; vertex stores scattered over unrelated pixels: 7.7 GB written per
+// launch against 1.7 GB of vertices).  So the automatic choice takes it in the serial order only.
+inline bool whole_subpaths(const cl2_renderer* r) {
+    return r->traversal_mode == 4 || (r->traversal_mode == 0 && !tree_in_lds(r) && !r->pipe_active);
 }
 // Two triangles per step of the persistent walk while the tree is cache-resident (the step is then
 // issue-bound and fewer, fatter steps win: glass +5 %, blob +4 %); one when it streams from memory
@@ -292,6 +302,41 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
         if (!split) r->launches_tp++;
         HIP_TRY(r, hipGetLastError());
     }
+    return CL2_OK;
+}
+
+// subpaths of every pixel: kinds = 1 light, 2 camera, 3 both (light first: one RNG stream per pixel)
+int launch_subpaths(cl2_renderer* r, hipStream_t st, const PathBufs* set, int kinds) {
+    if (!whole_subpaths(r)) {
+        int rc = CL2_OK;
+        if (kinds & 1) rc = launch_trace(r, CL2_LIGHT, st, set);
+        if (rc == CL2_OK && (kinds & 2)) rc = launch_trace(r, CL2_CAMERA, st, set);
+        return rc;
+    }
+    HIP_TRY(r, hipMemsetAsync(r->d_work, 0, sizeof(unsigned), st));
+    Timed t(r, ST_TRAVERSE_PATHS, st);
+    // lanes gathered / steps waited before a wave runs its bounce phase (debug_flags bits 16-22 / 24-30 override)
+    const int lanes = ((r->debug_flags >> 16) & 0x7F) ? ((r->debug_flags >> 16) & 0x7F) : 32;
+    const int wait = ((r->debug_flags >> 24) & 0x7F) ? ((r->debug_flags >> 24) & 0x7F) : 48;
+#define CL2_WHOLE(CNT, TWO, WPS)                                                                                         \
+    hipLaunchKernelGGL((k_subpaths_persistent<CNT, TWO, WPS>), dim3(grid), dim3(BLOCK), bvh_lds_bytes(r), st, r->bvh, \
+                       r->B, r->d_work, set[CL2_LIGHT], set[CL2_CAMERA], r->d_seeds, r->d_tri_shade, r->d_mats, r->n_mats, \
+                       r->d_stats, lanes, wait, kinds)
+    // experiment switch (debug_flags bits 13-15): register budget of the launch as waves per SIMD (4, 5, 6; 7 = 8 waves), 0 = default
+    const int wps_flag = (r->debug_flags >> 13) & 7;
+    const int wps = wps_flag == 7 ? 8 : (wps_flag ? wps_flag : 5);
+    // the grid holds as many workgroups as stay resident (4 waves each): wps per CU-quarter
+    const int grid = std::max(1, persistent_grid_paths(r) * std::min(wps, 8) / 8);
+#define CL2_WHOLE_W(WPS)                                                                                                 \
+    do {                                                                                                                 \
+        if (two_tris_per_step(r)) { if (r->counting) CL2_WHOLE(true, true, WPS); else CL2_WHOLE(false, true, WPS); }      \
+        else { if (r->counting) CL2_WHOLE(true, false, WPS); else CL2_WHOLE(false, false, WPS); }                         \
+    } while (0)
+    if (wps <= 4) CL2_WHOLE_W(4); else if (wps == 5) CL2_WHOLE_W(5); else if (wps == 6) CL2_WHOLE_W(6); else CL2_WHOLE_W(8);
+#undef CL2_WHOLE_W
+#undef CL2_WHOLE
+    r->launches_tp++;
+    HIP_TRY(r, hipGetLastError());
     return CL2_OK;
 }
 
@@ -725,8 +770,8 @@ int cl2_get_seeds(cl2_renderer* r, uint32_t* seeds, size_t n_words) {
 
 int cl2_make_light_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_generate(r, CL2_LIGHT, r->stream, r->sets[r->cur])); return drain(r); }
 int cl2_make_camera_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_generate(r, CL2_CAMERA, r->stream, r->sets[r->cur])); return drain(r); }
-int cl2_trace_light_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_trace(r, CL2_LIGHT, r->stream, r->sets[r->cur])); return drain(r); }
-int cl2_trace_camera_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_trace(r, CL2_CAMERA, r->stream, r->sets[r->cur])); return drain(r); }
+int cl2_trace_light_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_subpaths(r, r->stream, r->sets[r->cur], 1)); return drain(r); }
+int cl2_trace_camera_rays(cl2_renderer* r) { STAGE_PROLOGUE(r); TRY(launch_subpaths(r, r->stream, r->sets[r->cur], 2)); return drain(r); }
 int cl2_join_paths(cl2_renderer* r) {
     STAGE_PROLOGUE(r);
     TRY(launch_connect(r, r->stream, r->sets[r->cur], 0));
@@ -780,8 +825,7 @@ int run_chunk(cl2_renderer* r, bool pipe, int count) {
         if (pipe && i >= 3) HIP_TRY(r, hipStreamWaitEvent(r->stream, r->ev_res[(i - 3) % 6], 0));
         TRY(launch_generate(r, CL2_LIGHT, r->stream, set));
         TRY(launch_generate(r, CL2_CAMERA, r->stream, set));
-        TRY(launch_trace(r, CL2_LIGHT, r->stream, set));
-        TRY(launch_trace(r, CL2_CAMERA, r->stream, set));
+        TRY(launch_subpaths(r, r->stream, set, 3));
         if (pipe) {
             HIP_TRY(r, hipEventRecord(r->ev_paths[i % 3], r->stream));
             HIP_TRY(r, hipStreamWaitEvent(s_conn, r->ev_paths[i % 3], 0));
@@ -1066,7 +1110,7 @@ int cl2_probe_bounce(cl2_renderer* r, int from_camera, const float* in, size_t n
 }
 int cl2_set_traversal_mode(cl2_renderer* r, int mode) {
     if (!r) return CL2_E_INVALID;
-    if (mode < 0 || mode > 3) return fail(r, CL2_E_INVALID, "traversal mode must be 0 (auto), 1 (fused), 2 (persistent) or 3 (fused subpaths, persistent connection rays)");
+    if (mode < 0 || mode > 4) return fail(r, CL2_E_INVALID, "traversal mode must be 0 (auto), 1 (fused), 2 (persistent, per level), 3 (fused subpaths, persistent connection rays) or 4 (persistent whole subpaths)");
     r->traversal_mode = mode;
     r->paths_share = 0;
     return CL2_OK;

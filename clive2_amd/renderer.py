@@ -254,8 +254,8 @@ class Renderer:
         self._check(self._L.cl2_set_pipelining(self._h, int(stages)), "set_pipelining")
 
     def set_traversal_mode(self, mode):
-        """0 auto, 1 fused one-ray-per-lane kernels, 2 persistent traversal with ray replacement, 3 fused
-        subpaths + persistent connection rays."""
+        """0 auto, 1 fused one-ray-per-lane kernels, 2 persistent traversal with ray replacement (one launch per
+        level), 3 fused subpaths + persistent connection rays, 4 whole subpaths in one persistent launch."""
         self._check(self._L.cl2_set_traversal_mode(self._h, int(mode)), "set_traversal_mode")
 
     def set_debug_flags(self, flags):

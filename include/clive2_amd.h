@@ -111,8 +111,11 @@ int cl2_set_levels_per_launch(cl2_renderer* r, int levels);
 /* Traversal organisation: 1 = one ray per lane inside the subpath / connection kernels (best when the
  * tree is LDS-resident), 2 = persistent traversal launches with lane-level ray replacement + one
  * bounce launch per level (rays of very different cost: large trees), 3 = subpaths as in 1, connection
- * rays as in 2 (mid-size trees in serial order: no per-level launch tails), 0 (default) = 1 for
- * LDS-resident trees, otherwise 2.  Results are identical for every setting. */
+ * rays as in 2 (mid-size trees in serial order: no per-level launch tails), 4 = connection rays as in 2 and
+ * both subpaths of a pixel -- light, then camera, all levels -- walked by one lane of ONE persistent launch
+ * per sample, the bounces batched per wave (one launch tail instead of 24), 0 (default) = 1 for LDS-resident
+ * trees, otherwise 2 while the sample pipeline runs and 4 in serial order.  Results are identical for every
+ * setting. */
 int cl2_set_traversal_mode(cl2_renderer* r, int mode);
 /* Sample pipeline of cl2_run_samples.  The seed buffer is the only state one sample hands to the next
  * (src/renderer.py:86-87) and only the subpath stage (K1, K2, K3) touches it, so later stages of
@@ -190,7 +193,9 @@ int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
  * kernel (2 / 4: register budget; 7: one wave per camera vertex -- only in the test variant of the library,
  * libclive2_amd_test.so, built with -DCL2_TEST_VARIANT); bits 8-10 eighths of the wave slots given to the subpath stage while the sample
  * pipeline runs on a large scene (0 = tuned); bit 12 inverts the one/two-triangles-per-step choice of
- * the persistent walk. */
+ * the persistent walk; whole-subpath launch (mode 4): bits 13-15 register budget as waves per SIMD (4, 5, 6;
+ * 7 = 8; 0 = default 5), bits 16-22 lanes gathered before a wave runs its bounce phase (0 = default 32),
+ * bits 24-30 steps a finished lane waits at most (0 = default 48). */
 int cl2_set_debug_flags(cl2_renderer* r, int flags);
 int cl2_reset_counters(cl2_renderer* r);
 

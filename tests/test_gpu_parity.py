@@ -155,16 +155,19 @@ def test_levels_per_launch_is_a_pure_performance_knob(levels, glass_scene, oracl
         r.set_levels_per_launch(7)
 
 
-@pytest.mark.parametrize("flags", [0, 1 << 12])
+@pytest.mark.parametrize("mode", [2, 4])
+@pytest.mark.parametrize("flags", [0, 1 << 12, (4 << 13) | (1 << 16) | (1 << 24), (7 << 13) | (64 << 16) | (100 << 24) | (1 << 12)])
 @pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
-def test_persistent_traversal_mode_is_equivalent(scene_name, flags, request, oracle_mod):
+def test_persistent_traversal_mode_is_equivalent(scene_name, flags, mode, request, oracle_mod):
     """traversal_mode 2 (persistent launches with lane-level ray replacement + one bounce launch per
-    level, the large-scene organisation) reproduces the oracle exactly, like the fused mode -- in
-    both forms of its step (two triangles per step for cache-resident trees, bit 12 selects the
-    one-triangle form used for trees that stream from memory)."""
+    level) and 4 (whole subpaths, light then camera, in ONE persistent launch with the bounces batched per
+    wave: the large-scene organisation) reproduce the oracle exactly, like the fused mode -- in
+    both forms of the step (two triangles per step for cache-resident trees, bit 12 selects the
+    one-triangle form used for trees that stream from memory), and for any register budget (bits 13-15)
+    and bounce batching (bits 16-22: lanes gathered, bits 24-30: steps waited) of the whole-subpath launch."""
     scene = request.getfixturevalue(scene_name)
     r, o = _pair(scene, oracle_mod)
-    r.set_traversal_mode(2)
+    r.set_traversal_mode(mode)
     r.set_debug_flags(flags)
     _run_to_paths(r, o)
     for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
@@ -463,7 +466,7 @@ def test_movie_cli_writes_turntable_frames(tmp_path):
     assert not np.array_equal(frames[0], frames[1])        # the camera moved
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
 def test_sample_pipeline_is_a_pure_performance_knob(mode, glass_scene, oracle_mod):
     """run_samples as a pipeline over samples (later stages of sample i on their own streams beside
     the subpath stage of the next samples; 2 and 3 stages) == serial order == oracle: seeds, last
