@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_PKG, "libclive2_amd.so")
 # the test variant additionally carries the second implementation of the resolve stage
 # (csrc/connect_resolve_wide.hpp, -DCL2_TEST_VARIANT): a cross-check for tests, not shipped code
 TEST_LIB_PATH = os.path.join(_PKG, "libclive2_amd_test.so")
-_MAIN_SOURCE = os.path.join(_PKG, "csrc", "renderer_api.hip")
+_MAIN_SOURCES = [os.path.join(_PKG, "csrc", "renderer_api.hip"), os.path.join(_PKG, "csrc", "bvh_builder_gpu.hip")]
 _HEADER = os.path.join(os.path.dirname(_PKG), "include", "clive2_amd.h")
 
 
@@ -57,7 +57,7 @@ class Organisation(C.Structure):
 
 
 EXPORTS = [
-    "cl2_create", "cl2_destroy", "cl2_last_error", "cl2_abi_version", "cl2_build_bvh", "cl2_upload_scene", "cl2_set_seeds",
+    "cl2_create", "cl2_destroy", "cl2_last_error", "cl2_abi_version", "cl2_build_bvh", "cl2_build_bvh_gpu", "cl2_set_create_error", "cl2_upload_scene", "cl2_set_seeds",
     "cl2_get_seeds", "cl2_make_light_rays", "cl2_make_camera_rays", "cl2_trace_light_rays",
     "cl2_trace_camera_rays", "cl2_join_paths", "cl2_finalize_samples", "cl2_gather_light_image",
     "cl2_process_images", "cl2_run_samples", "cl2_set_levels_per_launch", "cl2_set_traversal_mode", "cl2_set_pipelining", "cl2_read_accumulators", "cl2_reset_accumulators",
@@ -88,7 +88,7 @@ def build(force=False, verbose=False, variant=None):
     path = _path(variant)
     if not force and not needs_build(variant):
         return path
-    cmd = ["hipcc"] + HIPCC_FLAGS + (["-DCL2_TEST_VARIANT"] if variant == "test" else []) + [_MAIN_SOURCE, "-o", path]
+    cmd = ["hipcc"] + HIPCC_FLAGS + (["-DCL2_TEST_VARIANT"] if variant == "test" else []) + _MAIN_SOURCES + ["-o", path]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RendererError("hipcc failed:\n" + res.stdout)

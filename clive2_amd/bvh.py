@@ -131,7 +131,9 @@ class _FlatTree:
         self.members = [None] * len(boxes)       # count_boxes() compatibility
 
 
-def _construct_native(root_box):
+def _construct_native(root_box, gpu=False, device=0):
+    """C++ builders of libclive2_amd.so: the host SAH builder (the reference's rule, O(n log n)) or, with `gpu`,
+    the LBVH builder on the GPU (another valid tree in the same convention, built in milliseconds)."""
     import ctypes as C
     from . import _native
     L = _native.lib()
@@ -141,12 +143,18 @@ def _construct_native(root_box):
     boxes = np.zeros(2 * n, dtype=struct_types.Box)
     perm = np.zeros(n, dtype=np.int64)
     n_boxes = C.c_int64(0)
-    L.cl2_build_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64,
-                                C.POINTER(C.c_int64), C.c_void_p]
-    rc = L.cl2_build_bvh(_native.ptr(tmin), _native.ptr(tmax), n, MAX_MEMBERS, MAX_DEPTH, _native.ptr(boxes),
-                         len(boxes), C.byref(n_boxes), _native.ptr(perm))
+    if gpu:
+        L.cl2_build_bvh_gpu.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                        C.POINTER(C.c_int64), C.c_void_p]
+        rc = L.cl2_build_bvh_gpu(int(device), _native.ptr(tmin), _native.ptr(tmax), n, MAX_MEMBERS, _native.ptr(boxes),
+                                 len(boxes), C.byref(n_boxes), _native.ptr(perm))
+    else:
+        L.cl2_build_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                    C.POINTER(C.c_int64), C.c_void_p]
+        rc = L.cl2_build_bvh(_native.ptr(tmin), _native.ptr(tmax), n, MAX_MEMBERS, MAX_DEPTH, _native.ptr(boxes),
+                             len(boxes), C.byref(n_boxes), _native.ptr(perm))
     if rc != 0:
-        raise _native.RendererError(f"cl2_build_bvh failed ({rc}): {L.cl2_last_error(None).decode()}")
+        raise _native.RendererError(f"cl2_build_bvh{'_gpu' if gpu else ''} failed ({rc}): {L.cl2_last_error(None).decode()}")
     root_box.tree = _FlatTree(root_box, boxes[:n_boxes.value].copy(), perm, 0)
     return root_box
 
@@ -158,7 +166,10 @@ def construct_BVH(root_box, builder="auto"):
 
     builder: "numpy" = this module's restatement (identical to the reference's tree, ties
     included); "native" = the C++ builder in libclive2_amd.so (same rule, O(n log n), equal
-    centroids ordered by id); "auto" = native above NATIVE_THRESHOLD triangles."""
+    centroids ordered by id); "auto" = native above NATIVE_THRESHOLD triangles; "gpu" = the LBVH builder on the
+    GPU (csrc/bvh_builder_gpu.hip): a different valid tree, for when set-up time matters (needs a GPU)."""
+    if builder == "gpu":
+        return _construct_native(root_box, gpu=True)
     if builder == "native" or (builder == "auto" and len(root_box) > NATIVE_THRESHOLD):
         return _construct_native(root_box)
     tree = _Tree(root_box)

@@ -472,6 +472,8 @@ int cl2_build_bvh(const double* tri_min, const double* tri_max, int64_t n_triang
     return CL2_OK;
 }
 
+void cl2_set_create_error(const char* msg) { g_create_error = msg ? msg : ""; }   // for the entry points of other translation units
+
 const char* cl2_last_error(const cl2_renderer* r) { return r ? r->err.c_str() : g_create_error.c_str(); }
 
 int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_renderer** out) {

@@ -67,6 +67,11 @@ def finish_exchange(rank, path=None):
 
 def join_communicator(renderer, rank, world_size, path=None, timeout=180.0):
     """The whole bootstrap for one rank: id from rank 0, `comm_init` (collective), clean-up."""
+    # All ranks of this job are processes of ONE node (the id travels through a local file), so RCCL's own
+    # bootstrap sockets can always use the loopback interface -- the container's hostname need not resolve and
+    # no other interface need exist.  An explicit NCCL_SOCKET_IFNAME in the environment wins.
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC between the ranks' processes on this pool
     n = renderer._L.cl2_comm_unique_id_bytes()
     uid = exchange_unique_id(rank, world_size, renderer.comm_unique_id, n, path=path, timeout=timeout)
     renderer.comm_init(rank, world_size, uid)
