@@ -93,14 +93,10 @@ __device__ __forceinline__ unsigned block_compact_index(bool pred, unsigned* cou
 
 // ---------------------------------------------------------------- K1: generate_light_rays
 // trace.metal:1070-1124.  Writes vertex slot 0 of the light subpath.
-__global__ __launch_bounds__(BLOCK) void k_gen_light_rays(
-        int B, const float4* __restrict__ light_tris /*5 float4 per light: v0, v1, v2, normal, {material}*/,
-        const float* __restrict__ light_areas, const int* __restrict__ light_tri_index,
-        const MaterialDev* __restrict__ mats, int light_count, uint2* __restrict__ seeds, PathBufs pb) {
-    const int id = blockIdx.x * BLOCK + threadIdx.x;
-    if (id >= B) return;
-    uint2 sd = seeds[id];
-    uint32_t seed0 = sd.x, seed1 = sd.y;
+__device__ __forceinline__ void gen_light_ray(int id, const float4* __restrict__ light_tris /*5 float4 per light: v0, v1, v2, normal, {material}*/,
+                                              const float* __restrict__ light_areas, const int* __restrict__ light_tri_index,
+                                              const MaterialDev* __restrict__ mats, int light_count, uint32_t& seed0, uint32_t& seed1,
+                                              const PathBufs& pb) {
     int li = (int)(xorshift_random(seed0) * light_count);
     if (li > light_count - 1) li = light_count - 1;     // the draw can be exactly 1.0
     const float4 a0 = light_tris[5 * li], a1 = light_tris[5 * li + 1], a2 = light_tris[5 * li + 2],
@@ -127,16 +123,22 @@ __global__ __launch_bounds__(BLOCK) void k_gen_light_rays(
     pb.tri[id] = light_tri_index[li];
     pb.len[id] = 0;
     pb.carry[id] = 1.0f / (2.0f * PI_F);          // new_ray.l_importance, trace.metal:401
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gen_light_rays(
+        int B, const float4* __restrict__ light_tris, const float* __restrict__ light_areas, const int* __restrict__ light_tri_index,
+        const MaterialDev* __restrict__ mats, int light_count, uint2* __restrict__ seeds, PathBufs pb) {
+    const int id = blockIdx.x * BLOCK + threadIdx.x;
+    if (id >= B) return;
+    uint2 sd = seeds[id];
+    uint32_t seed0 = sd.x, seed1 = sd.y;
+    gen_light_ray(id, light_tris, light_areas, light_tri_index, mats, light_count, seed0, seed1, pb);
     seeds[id] = make_uint2(seed0, seed1);
 }
 
 // ---------------------------------------------------------------- K2: generate_camera_rays
 // trace.metal:1020-1067 with indices[id] == id (renderer.py:92-94).
-__global__ __launch_bounds__(BLOCK) void k_gen_camera_rays(int B, CameraRec c, uint2* __restrict__ seeds, PathBufs pb) {
-    const int id = blockIdx.x * BLOCK + threadIdx.x;
-    if (id >= B) return;
-    uint2 sd = seeds[id];
-    uint32_t seed0 = sd.x, seed1 = sd.y;
+__device__ __forceinline__ void gen_camera_ray(int id, const CameraRec& c, uint32_t& seed0, uint32_t& seed1, const PathBufs& pb) {
     const float x_offset = xorshift_random(seed0);
     const float y_offset = xorshift_random(seed1);
     const int pixel_x = id % c.pixel_width, pixel_y = id / c.pixel_width;
@@ -154,6 +156,28 @@ __global__ __launch_bounds__(BLOCK) void k_gen_camera_rays(int B, CameraRec c, u
     pb.tri[id] = -1;
     pb.len[id] = 0;
     pb.carry[id] = c_imp;                         // new_ray.c_importance, trace.metal:404
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gen_camera_rays(int B, CameraRec c, uint2* __restrict__ seeds, PathBufs pb) {
+    const int id = blockIdx.x * BLOCK + threadIdx.x;
+    if (id >= B) return;
+    uint2 sd = seeds[id];
+    uint32_t seed0 = sd.x, seed1 = sd.y;
+    gen_camera_ray(id, c, seed0, seed1, pb);
+    seeds[id] = make_uint2(seed0, seed1);
+}
+
+// K1 then K2 for the same pixel in one launch (cl2_run_samples): the pixel's RNG state goes from the light-ray draws to
+// the camera-ray draws in registers, as make_light_rays followed by make_camera_rays leaves it (renderer.py:281-283).
+__global__ __launch_bounds__(BLOCK) void k_gen_rays(
+        int B, const float4* __restrict__ light_tris, const float* __restrict__ light_areas, const int* __restrict__ light_tri_index,
+        const MaterialDev* __restrict__ mats, int light_count, CameraRec c, uint2* __restrict__ seeds, PathBufs lp, PathBufs cp) {
+    const int id = blockIdx.x * BLOCK + threadIdx.x;
+    if (id >= B) return;
+    uint2 sd = seeds[id];
+    uint32_t seed0 = sd.x, seed1 = sd.y;
+    gen_light_ray(id, light_tris, light_areas, light_tri_index, mats, light_count, seed0, seed1, lp);
+    gen_camera_ray(id, c, seed0, seed1, cp);
     seeds[id] = make_uint2(seed0, seed1);
 }
 
@@ -229,8 +253,11 @@ struct ConnRaySource {          // connection rays: tag {slot, pixel} -> light v
     }
 };
 
+// SGPR budget: 256-thread workgroups are admitted per CU up to floor(800 / (ceil(sgprs / 16) * 16 + 16)) -- 8 up to 80
+// SGPRs, 7 from 81 (MI355X_MICROARCH.md, "Residency").  Left alone the compiler takes 81 for the connection-ray
+// instantiation: one workgroup in eight of the persistent grid then never becomes resident beside the others.
 template <bool COUNT, bool TWO_TRIS, class Source>
-__global__ __launch_bounds__(BLOCK) void k_traverse_persistent(BvhView bvh, const unsigned* __restrict__ count,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(78))) void k_traverse_persistent(BvhView bvh, const unsigned* __restrict__ count,
                                                               unsigned* __restrict__ work_counter, Source src, Stats* stats,
                                                               int is_conn) {
     BvhLds lds{nullptr, nullptr};
@@ -851,6 +878,39 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(int B, const float4* __res
     acc[(size_t)1 * B + id] += scrub(l.y + f.y);
     acc[(size_t)2 * B + id] += scrub(l.z + f.z);
     acc[(size_t)3 * B + id] += sample_w[id] + l.w;      // K8's `sum_weights[id] += weight_sum`, :963
+    acc[(size_t)4 * B + id] += scrub(u.x);
+    acc[(size_t)5 * B + id] += scrub(u.y);
+    acc[(size_t)6 * B + id] += scrub(u.z);
+    acc[(size_t)7 * B + id] += 1.0f;
+    light_image[id] = make_float4(0, 0, 0, 0);
+}
+
+// K6 + process_images in one launch for cl2_run_samples: the filtered sample goes straight from registers into the
+// accumulators (the per-sample images finalized / sample_weights are not written: they are what the stage calls
+// cl2_finalize_samples / cl2_process_images exchange, 36 B per pixel and a launch boundary per sample).
+// Same statements in the same order as k_finalize followed by k_accumulate.
+__global__ __launch_bounds__(BLOCK) void k_finalize_accumulate(int B, int W, int H, const float* __restrict__ agg,
+                                                               float4* __restrict__ light_image, const float4* __restrict__ uni,
+                                                               float* __restrict__ acc) {
+    const int id = blockIdx.x * BLOCK + threadIdx.x;
+    if (id >= B) return;
+    V3 total = v3(0, 0, 0);
+    float wsum = 0.0f;
+    for (int i = -1; i < 2; i++) {
+        for (int j = -1; j < 2; j++) {
+            const int sx = (id % W) + i, sy = (id / W) + j;
+            if (sx < 0 || sx >= W || sy < 0 || sy >= H) continue;
+            const size_t k = (size_t)sy * W + sx;
+            const float weight = agg[(size_t)((1 - i) * 3 + (1 - j)) * B + k];
+            total = total + weight * v3(agg[(size_t)9 * B + k], agg[(size_t)10 * B + k], agg[(size_t)11 * B + k]);
+            wsum += weight * agg[(size_t)12 * B + k];
+        }
+    }
+    const float4 l = light_image[id], u = uni[id];
+    acc[(size_t)0 * B + id] += scrub(l.x + total.x);
+    acc[(size_t)1 * B + id] += scrub(l.y + total.y);
+    acc[(size_t)2 * B + id] += scrub(l.z + total.z);
+    acc[(size_t)3 * B + id] += wsum + l.w;
     acc[(size_t)4 * B + id] += scrub(u.x);
     acc[(size_t)5 * B + id] += scrub(u.y);
     acc[(size_t)6 * B + id] += scrub(u.z);

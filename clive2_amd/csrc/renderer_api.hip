@@ -114,6 +114,12 @@ namespace {
         }                                                                                         \
     } while (0)
 
+#define TRY(expr)                         \
+    do {                                  \
+        int rc_ = (expr);                 \
+        if (rc_ != CL2_OK) return rc_;    \
+    } while (0)
+
 template <typename T> int dev_alloc(cl2_renderer* r, T** p, size_t count) {
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
@@ -185,6 +191,14 @@ int launch_generate(cl2_renderer* r, int which, hipStream_t st, const PathBufs* 
     else
         hipLaunchKernelGGL(k_gen_camera_rays, dim3(grid_for(r->B)), dim3(BLOCK), 0, st, r->B, r->cam, r->d_seeds,
                            set[CL2_CAMERA]);
+    HIP_TRY(r, hipGetLastError());
+    return CL2_OK;
+}
+
+int launch_generate_both(cl2_renderer* r, hipStream_t st, const PathBufs* set) {
+    Timed t(r, ST_GENERATE, st);
+    hipLaunchKernelGGL(k_gen_rays, dim3(grid_for(r->B)), dim3(BLOCK), 0, st, r->B, r->d_light_tris, r->d_light_areas,
+                       r->d_light_tri_index, r->d_mats, r->light_count, r->cam, r->d_seeds, set[CL2_LIGHT], set[CL2_CAMERA]);
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;
 }
@@ -425,6 +439,14 @@ int launch_accumulate(cl2_renderer* r, hipStream_t st) {
     return CL2_OK;
 }
 
+int launch_finalize_accumulate(cl2_renderer* r, hipStream_t st) {
+    Timed t(r, ST_FINALIZE, st);
+    hipLaunchKernelGGL(k_finalize_accumulate, dim3(grid_for(r->B)), dim3(BLOCK), 0, st, r->B, r->W, r->H, r->d_agg, r->d_light_image,
+                       r->d_uni, r->d_acc);
+    HIP_TRY(r, hipGetLastError());
+    return CL2_OK;
+}
+
 int need_scene(cl2_renderer* r) {
     if (!r) return CL2_E_INVALID;
     r->pipe_active = false;
@@ -436,11 +458,6 @@ int need_scene(cl2_renderer* r) {
 #define STAGE_PROLOGUE(r)                 \
     do {                                  \
         int rc_ = need_scene(r);          \
-        if (rc_ != CL2_OK) return rc_;    \
-    } while (0)
-#define TRY(expr)                         \
-    do {                                  \
-        int rc_ = (expr);                 \
         if (rc_ != CL2_OK) return rc_;    \
     } while (0)
 
@@ -825,8 +842,7 @@ int run_chunk(cl2_renderer* r, bool pipe, int count) {
         hipStream_t s_res = pipe ? (pipeline_stages(r) == 2 ? r->stream_res : r->stream_conn) : r->stream;
         // resolve of sample i-3 was the last reader of this subpath set
         if (pipe && i >= 3) HIP_TRY(r, hipStreamWaitEvent(r->stream, r->ev_res[(i - 3) % 6], 0));
-        TRY(launch_generate(r, CL2_LIGHT, r->stream, set));
-        TRY(launch_generate(r, CL2_CAMERA, r->stream, set));
+        TRY(launch_generate_both(r, r->stream, set));
         TRY(launch_subpaths(r, r->stream, set, 3));
         if (pipe) {
             HIP_TRY(r, hipEventRecord(r->ev_paths[i % 3], r->stream));
@@ -840,8 +856,7 @@ int run_chunk(cl2_renderer* r, bool pipe, int count) {
             HIP_TRY(r, hipStreamWaitEvent(s_res, r->ev_conn[i & 1], 0));
         }
         TRY(launch_resolve(r, s_res, set, cs));
-        TRY(launch_finalize(r, s_res));
-        TRY(launch_accumulate(r, s_res));
+        TRY(launch_finalize_accumulate(r, s_res));
         if (pipe) HIP_TRY(r, hipEventRecord(r->ev_res[i % 6], s_res));
         r->samples++;
         // bound the number of in-flight event pairs while profiling

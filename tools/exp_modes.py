@@ -11,10 +11,14 @@ def run(scene, W, H, mode, flags, pipelining, n):
     r.set_traversal_mode(mode); r.set_debug_flags(flags); r.set_pipelining(pipelining)
     r.run_samples(4)
     r.reset_counters()
+    if pipelining == 0:
+        r.set_profiling(2)
     t0 = time.perf_counter()
     r.run_samples(n)
     dt = time.perf_counter() - t0
-    rays = r.counters()["rays"]
+    c = r.counters()
+    rays = c["rays"]
+    run.last = {k[3:]: round(c[k] / n, 3) for k in c if k.startswith("ms_") and c[k] > 0}
     uni = r.read_accumulators()[3].copy()
     org = r.organisation()
     r.close()
@@ -33,7 +37,7 @@ def main():
         ms, gr, uni, org = run(scene, W, H, mode, flags, pipe, n)
         ref = uni if ref is None else ref
         print(f"mode {mode} flags {flags:#x} pipe {pipe}: {ms:8.3f} ms {gr:6.3f} Grays/s  {'same' if uni.tobytes() == ref.tobytes() else 'DIFFERENT'}  "
-              f"window {org['n_lds_records']} share {org['paths_share']}", flush=True)
+              f"window {org['n_lds_records']} share {org['paths_share']} {run.last}", flush=True)
 
 
 if __name__ == "__main__":
