@@ -102,6 +102,42 @@ def _sweep_split(mins, maxes):
     return best
 
 
+def spatial_split(soup, ids=None):
+    """`spatial_split` of the reference (bvh.py:194-285) AS WRITTEN: nine candidate planes per axis at 10 %..90 % of
+    the node's extent; the left child takes the triangles that end before the plane (prefix of the order by max), the
+    right child those that start behind it (suffix of the order by min).  Returns (cost, left ids, right ids), or
+    (inf, None, None) when no plane separates anything.
+
+    Dead code in the reference: its only call is commented out (bvh.py:298-299), and it cannot be switched on there
+    (quirk Q19) -- triangles that straddle the chosen plane go to NEITHER child (`split_tris` is computed and dropped),
+    so np_flatten_bvh's own count assertion (bvh.py:387) fails on the first such split; the children's bounds are also
+    reduced over axes (0, 2) of the (triangle, vertex, xyz) array, i.e. over coordinates instead of vertices.
+    Restated expression for expression and pinned against the reference's function (tests/golden/spatial_split.npz);
+    like the reference, no builder uses it."""
+    ids = np.arange(len(soup)) if ids is None else np.asarray(ids)
+    mins, maxes, tris = soup.mins[ids], soup.maxes[ids], soup.triangles[ids]
+    box_min, box_max = mins.min(axis=0), maxes.max(axis=0)
+    box_span = box_max - box_min
+    n = len(ids)
+    best = (np.inf, None, None)
+    for axis in range(3):
+        by_min, by_max = np.argsort(mins[:, axis]), np.argsort(maxes[:, axis])
+        mins_sorted, maxes_sorted = mins[by_min], maxes[by_max]
+        for frac in np.arange(0.1, 1, 0.1):
+            plane = box_min[axis] + frac * box_span[axis]
+            first_behind = np.searchsorted(mins_sorted[:, axis], plane, side="left")
+            n_before = np.searchsorted(maxes_sorted[:, axis], plane, side="right")
+            n_behind = n - first_behind
+            if n_behind == 0 or n_before == 0:
+                continue
+            before, behind = tris[by_max[:n_before]], tris[by_min[first_behind:]]
+            cost = (surface_area(np.min(behind, axis=(0, 2)), np.max(behind, axis=(0, 2))) * n_behind
+                    + surface_area(np.min(before, axis=(0, 2)), np.max(before, axis=(0, 2))) * n_before)
+            if cost < best[0]:
+                best = (cost, ids[by_max[:n_before]], ids[by_min[first_behind:]])
+    return best
+
+
 class _Tree:
     """Parallel-list binary tree over index vectors into one soup."""
 

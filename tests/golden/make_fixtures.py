@@ -117,6 +117,29 @@ def mesh_fixture(ref_scene, ref_load, ref_bvh, ref_camera, subdiv, w, h):
                 n_boxes=np.int32(len(np_boxes)), n_triangles=np.int32(len(np_tris)))
 
 
+def spatial_fixture(ref_load, ref_bvh, ref_camera, w, h):
+    """Outputs of the reference's `spatial_split` (bvh.py:194-285; dead code there: its call in construct_BVH is
+    commented out, bvh.py:298-299) on a few soups: the Cornell box + an icosphere, and the two children of its first
+    object split.  Stored: the soup (vertices/faces to rebuild it), the returned cost and the children's triangles."""
+    verts, faces = icosphere(1)
+    verts = verts * 2.0 + np.array([0.0, 1.0, 0.0])
+    out = dict(vertices=verts, faces=faces)
+    with contextlib.redirect_stdout(io.StringIO()):
+        cam = ref_camera.Camera(center=np.array([0, 1.5, 6]), direction=np.array([0, 0, -1]),
+                                pixel_width=w, pixel_height=h, phys_width=w / h, phys_height=1)
+        tris = list(ref_load.camera_geometry(cam)) + list(ref_load.triangles_for_box())
+        root = ref_bvh.FastTreeBox.from_triangle_objects(tris) + ref_load.fast_load(verts, faces, material=5)
+        _, obj_l, obj_r = ref_bvh.object_split(root)
+        room = ref_bvh.FastTreeBox.from_triangle_objects(tris)
+        for name, box in (("root", root), ("left", obj_l), ("right", obj_r), ("room", room)):
+            cost, l, r = ref_bvh.spatial_split(box)
+            out[name + "_in"] = np.asarray(box.triangles)
+            out[name + "_cost"] = np.float64(cost)
+            out[name + "_l"] = np.asarray(l.triangles) if l is not None else np.zeros((0, 3, 3))
+            out[name + "_r"] = np.asarray(r.triangles) if r is not None else np.zeros((0, 3, 3))
+    return out
+
+
 def renderer_glue_fixture(ref_scene, ref_renderer, w, h, seed):
     """The numpy host glue of the reference's Renderer (renderer.py:11-13, :63, :97-111, :253-316) run on
     seeded stand-ins for the device buffers: light-image indices with negative (unused) and >= W*H
@@ -194,6 +217,8 @@ def main():
     for subdiv in (1, 2):
         np.savez_compressed(os.path.join(OUT, f"cornell_icosphere{subdiv}_64x48.npz"),
                             **mesh_fixture(ref_scene, ref_load, ref_bvh, ref_camera, subdiv, 64, 48))
+
+    np.savez_compressed(os.path.join(OUT, "spatial_split.npz"), **spatial_fixture(ref_load, ref_bvh, ref_camera, 64, 48))
 
     # tone_map (camera.py:73-82) on a small seeded image: output-stage fixture
     rng = np.random.RandomState(7)
