@@ -1,0 +1,168 @@
+// bvh_wide.hpp -- persistent closest-hit walk over a 4-wide collapse of the reference's binary tree, with the
+// reference's decisions (trace.metal:144-176) reproduced exactly.
+//
+// Why it is exact.  The reference pops a box, tests it (`tmin <= tmax && tmin < best_t`, tmin/tmax from the slab test),
+// and either pushes its two children (the one at left+1 is popped first) or tests the leaf's triangles in order.  A box
+// nests its children exactly: bounds are min/max over nested triangle sets, rounded float64 -> float32 monotonically
+// (cl2_upload_scene verifies it box by box and disables this walk otherwise).  For a ray with finite 1/d every slab
+// value is a monotonic function of the bound it comes from, so a child's tmin is >= and its tmax <= its parent's, and
+// best_t only ever shrinks.  Hence: if a box passes its test at the time it is popped, every ancestor passed its own
+// test earlier; if an inner box fails, every box below it fails too.  The inner tests therefore decide nothing that
+// the tests of the boxes below do not decide again: they only prune.  A wide node stores the boxes of the (up to four)
+// grandchildren of a reference box in the reference's visit order; the walk computes their slab values in one visit,
+// pushes the ones that pass with their entry distance, and re-applies `tmin < best_t` when an entry is popped -- the
+// reference's own test of that box at that moment.  Leaves are visited in the reference's order against the
+// reference's best_t, so hits (exact-t ties included) are identical; what changes is the number of dependent fetches
+// (one 128-byte line per two levels) and of loop passes.
+//
+// Rays with a non-finite 1/d (a direction component is exactly 0: 0 * inf = NaN breaks the monotonicity argument)
+// are not walked here: their queue positions go to a left-over list that the binary walk (traverse_persistent)
+// processes afterwards.
+//
+// Wide node = 8 x float4: {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]} {hi.z[4]} {ref[4] as int} {pad}
+//   ref >= 0: wide node index; ref < 0 and != WIDE_EMPTY: leaf, ~ref = first_triangle << 4 | count - 1; WIDE_EMPTY: no slot.
+// Per-lane stack of {ref, tmin}: the first WIDE_STACK_LDS entries in LDS ([entry][thread], conflict-free), deeper ones
+// in a per-lane global array (rare: the dynamic depth of a 4-wide walk is mostly 2..6).
+#pragma once
+#include "bvh_traverse.hpp"
+
+namespace cl2 {
+
+constexpr int WIDE_EMPTY = (int)0x80000000;
+constexpr int WIDE_STACK_LDS = 8;
+constexpr int WIDE_STACK_OVERFLOW = 136;      // 2 x the reference's 64-entry stack bound + slack: cannot be exceeded (Q18 check at upload)
+
+struct WideView {
+    const float4* nodes;       // 8 float4 per wide node
+    const float4* tris;        // 3 float4 per triangle (the binary walk's array)
+    float4 root_lo, root_hi;   // the root box: tested once per ray, as the reference does
+    int2* overflow;            // [lanes of the launch][WIDE_STACK_OVERFLOW]
+    unsigned* leftover;        // queue positions of rays with a non-finite 1/d ...
+    unsigned* leftover_count;  // ... and how many
+};
+
+template <bool COUNT, bool TWO_TRIS, class Source>
+__device__ __forceinline__ void traverse_wide_persistent(const WideView& w, unsigned n, unsigned* work_counter, const Source& src,
+                                                         unsigned& n_box, unsigned& n_tri) {
+    extern __shared__ float4 cl2_tree_lds[];
+    int* s_ref = reinterpret_cast<int*>(cl2_tree_lds);                                  // [WIDE_STACK_LDS][blockDim.x]
+    float* s_tmin = reinterpret_cast<float*>(cl2_tree_lds) + WIDE_STACK_LDS * blockDim.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int2* ovf = w.overflow + ((size_t)blockIdx.x * nt + tid) * WIDE_STACK_OVERFLOW;
+    const int lane = tid & 63;
+    const unsigned waves = gridDim.x * (blockDim.x >> 6);
+    unsigned chunk = n / (waves * 4u);
+    chunk = chunk < 64u ? 64u : (chunk > (unsigned)RAY_CHUNK_MAX ? (unsigned)RAY_CHUNK_MAX : chunk);
+    unsigned w_next = 0, w_end = 0;
+    bool dry = false;
+    // per-lane ray state
+    bool active = false;
+    V3 o = v3(0, 0, 0), d = o, inv = o;
+    Hit best{-1, __builtin_inff(), 0.0f, 0.0f};
+    int cur = -1, tri_i = 0, tri_end = 0, sp = 0;
+    unsigned key = 0;
+
+    auto push = [&](int ref, float tmin) {
+        if (sp < WIDE_STACK_LDS) { s_ref[sp * nt + tid] = ref; s_tmin[sp * nt + tid] = tmin; }
+        else ovf[sp - WIDE_STACK_LDS] = make_int2(ref, __float_as_int(tmin));
+        sp++;
+    };
+    // next work item of the lane: pops until an entry still passes `tmin < best_t` (the reference's test of that box
+    // at this moment) or the stack is empty
+    auto pop_next = [&]() {
+        while (sp > 0 && cur < 0 && tri_i >= tri_end) {
+            sp--;
+            int ref; float tmin;
+            if (sp < WIDE_STACK_LDS) { ref = s_ref[sp * nt + tid]; tmin = s_tmin[sp * nt + tid]; }
+            else { const int2 e = ovf[sp - WIDE_STACK_LDS]; ref = e.x; tmin = __int_as_float(e.y); }
+            if (!(tmin < best.t)) continue;
+            if (ref >= 0) cur = ref;
+            else { const int info = ~ref; tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
+        }
+    };
+
+    while (true) {
+        // ---- refill idle lanes ----
+        unsigned long long idle = __ballot(!active);
+        while (idle && !dry) {
+            if (w_next >= w_end) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(work_counter, chunk);
+                base = __shfl(base, 0);
+                if (base >= n) { dry = true; break; }
+                w_next = base;
+                w_end = base + chunk < n ? base + chunk : n;
+            }
+            const unsigned avail = w_end - w_next;
+            const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
+            if (!active && rank < avail) {
+                key = w_next + rank;
+                src.load(key, o, d);
+                inv = rcp3(d);
+                if (!finite3(inv)) {
+                    w.leftover[atomicAdd(w.leftover_count, 1u)] = key;      // walked by the binary kernel afterwards
+                } else {
+                    best = Hit{-1, __builtin_inff(), 0.0f, 0.0f};
+                    cur = -1; tri_i = 0; tri_end = 0; sp = 0;
+                    // the root box, trace.metal:150-156 with best_t = inf
+                    const float t0x = (w.root_lo.x - o.x) * inv.x, t0y = (w.root_lo.y - o.y) * inv.y, t0z = (w.root_lo.z - o.z) * inv.z;
+                    const float t1x = (w.root_hi.x - o.x) * inv.x, t1y = (w.root_hi.y - o.y) * inv.y, t1z = (w.root_hi.z - o.z) * inv.z;
+                    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                                                       __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
+                    const float tmax = __builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
+                    if (COUNT) n_box++;
+                    if (tmin <= tmax && tmin < best.t) cur = 0;
+                    active = true;
+                }
+            }
+            const unsigned taken = __popcll(idle) < avail ? __popcll(idle) : avail;
+            w_next += taken;
+            idle = __ballot(!active);
+        }
+        if (!__any(active)) break;
+
+        if (active) {
+            pop_next();                                                     // lanes that finished a leaf in the previous pass
+            if (cur >= 0) {
+                // one wide node: the slab tests of up to four boxes, in the reference's visit order (slot 0 first)
+                const float4* nd = w.nodes + (size_t)8 * cur;
+                const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
+                const float4 rf = nd[6];
+                cur = -1;
+                const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
+                const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
+                const int ref[4] = {__float_as_int(rf.x), __float_as_int(rf.y), __float_as_int(rf.z), __float_as_int(rf.w)};
+#pragma unroll
+                for (int k = 3; k >= 0; k--) {                               // pushed last = popped first
+                    if (ref[k] == WIDE_EMPTY) continue;
+                    const float t0x = (lox[k] - o.x) * inv.x, t0y = (loy[k] - o.y) * inv.y, t0z = (loz[k] - o.z) * inv.z;
+                    const float t1x = (hix[k] - o.x) * inv.x, t1y = (hiy[k] - o.y) * inv.y, t1z = (hiz[k] - o.z) * inv.z;
+                    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                                                       __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
+                    const float tmax = __builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
+                    if (COUNT) n_box++;
+                    if (tmin <= tmax && tmin < best.t) push(ref[k], tmin);
+                }
+                pop_next();
+            }
+            if (tri_i < tri_end) {
+                const int i0 = tri_i;
+                const bool two = TWO_TRIS && i0 + 1 < tri_end;
+                const int i1 = two ? i0 + 1 : i0;
+                tri_i = i1 + 1;
+                float4 a0, a1, a2, c0, c1, c2;
+                a0 = w.tris[3 * i0]; a1 = w.tris[3 * i0 + 1]; a2 = w.tris[3 * i0 + 2];
+                if (TWO_TRIS) { c0 = w.tris[3 * i1]; c1 = w.tris[3 * i1 + 1]; c2 = w.tris[3 * i1 + 2]; }
+                if (COUNT) n_tri += two ? 2 : 1;
+                tri_test(o, d, a0, a1, a2, i0, best);
+                if (TWO_TRIS && two) tri_test(o, d, c0, c1, c2, i1, best);
+            }
+            if (tri_i >= tri_end && cur < 0 && sp == 0) {
+                src.store(key, best);
+                active = false;
+            }
+        }
+    }
+}
+
+}  // namespace cl2

@@ -34,6 +34,7 @@
 #include "detmath.hpp"
 #include "bsdf.hpp"
 #include "bvh_traverse.hpp"
+#include "bvh_wide.hpp"
 
 namespace cl2 {
 
@@ -214,7 +215,8 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_paths(
 // ---------------------------------------------------------------- persistent traversal kernels (large scenes)
 struct PathRaySource {          // subpath rays: queue entry -> pixel -> (P0.xyz, P1.xyz) of one level
     const int* queue; const float4* P0v; const float4* P1v; float4* hit;
-    __device__ __forceinline__ int pid(unsigned j) const { return queue ? queue[j] : (int)j; }
+    const unsigned* remap;      // non-null: ray j of this launch is queue position remap[j] (left-over list of the wide walk)
+    __device__ __forceinline__ int pid(unsigned j) const { if (remap) j = remap[j]; return queue ? queue[j] : (int)j; }
     __device__ __forceinline__ void load(unsigned j, V3& o, V3& d) const { const int p = pid(j); o = v3(P0v[p]); d = v3(P1v[p]); }
     __device__ __forceinline__ void store(unsigned j, const Hit& h) const {
         hit[pid(j)] = make_float4(__int_as_float(h.tri), h.t, h.u, h.v);
@@ -237,8 +239,9 @@ __device__ __forceinline__ float2 chit_load(const float2* chit, int B, int t, in
 
 struct ConnRaySource {          // connection rays: tag {slot, pixel} -> light vertex s-1 toward focal point / camera vertex t-1
     const int* ctag; const float4* LP0; const float4* CP0; float2* chit; V3 focal; int B;
+    const unsigned* remap;      // as in PathRaySource
     __device__ __forceinline__ void load(unsigned j, V3& o, V3& d) const {
-        const int tag = ctag[j];
+        const int tag = ctag[remap ? remap[j] : j];
         const int pid = tag & ((1 << TAG_PID_BITS) - 1), slot = (unsigned)tag >> TAG_PID_BITS;
         const int t = slot / 6 + 1, s = slot % 6 + 1;
         o = v3(LP0[(size_t)(s - 1) * B + pid]);
@@ -247,7 +250,7 @@ struct ConnRaySource {          // connection rays: tag {slot, pixel} -> light v
         d = normalize(target - o);
     }
     __device__ __forceinline__ void store(unsigned j, const Hit& h) const {
-        const int tag = ctag[j];
+        const int tag = ctag[remap ? remap[j] : j];
         const int pid = tag & ((1 << TAG_PID_BITS) - 1), slot = (unsigned)tag >> TAG_PID_BITS;
         chit_store(chit, B, slot, pid, h.tri, h.t);
     }
@@ -272,10 +275,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(78))) void k_
             atomicAdd(&stats->tri_tests, (unsigned long long)nt);
         }
     }
+    if (is_conn >= 0 && blockIdx.x == 0 && threadIdx.x == 0) {      // is_conn < 0: left-over launch of a wide walk, tallied there
+        atomicAdd(&stats->rays, (unsigned long long)n);
+        if (is_conn > 0) atomicAdd(&stats->conn_rays, (unsigned long long)n);
+        if (COUNT) atomicAdd(&stats->counted_rays, (unsigned long long)n);
+    }
+}
+
+// The same launch shape over the 4-wide collapse of the tree (bvh_wide.hpp): exact, half the dependent fetches.
+template <bool TWO_TRIS, class Source>
+__global__ __launch_bounds__(BLOCK, 8) __attribute__((amdgpu_num_sgpr(78))) void k_traverse_wide(WideView wide, const unsigned* __restrict__ count,
+                                                        unsigned* __restrict__ work_counter, Source src, Stats* stats, int is_conn) {
+    const unsigned n = *count;
+    unsigned nb = 0, nt = 0;
+    traverse_wide_persistent<false, TWO_TRIS>(wide, n, work_counter, src, nb, nt);
+    // all n rays of the launch are tallied here, the left-over ones included (their binary launch runs with is_conn < 0)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&stats->rays, (unsigned long long)n);
         if (is_conn) atomicAdd(&stats->conn_rays, (unsigned long long)n);
-        if (COUNT) atomicAdd(&stats->counted_rays, (unsigned long long)n);
     }
 }
 

@@ -68,6 +68,13 @@ struct cl2_renderer {
     MaterialDev* d_mats = nullptr;
     int n_mats = 0, light_count = 0;
     int n_top = 0;                       // boxes of the top levels renumbered to the front of the record array (0: plain visit order)
+    // 4-wide collapse of the tree for the exact wide walk (bvh_wide.hpp); n_wide == 0: not available for this scene
+    float4* d_wide = nullptr;
+    int n_wide = 0;
+    WideView wide{};
+    int2* d_wide_ovf = nullptr;          // per-lane stack overflow of the wide launches (one region per stage: [2])
+    unsigned* d_leftover[2] = {nullptr, nullptr};   // [0] subpath stage, [1] connection stage: queue positions + count
+    unsigned* d_leftover_count = nullptr;            // [2]
     CameraRec cam{};
 
     // state
@@ -138,6 +145,7 @@ template <typename T> void dev_free(cl2_renderer* r, T*& p) {
 }
 
 int fail(cl2_renderer* r, int code, const std::string& msg) { r->err = msg; return code; }
+inline float as_f_int(int32_t i) { float f; std::memcpy(&f, &i, 4); return f; }
 
 inline int grid_for(size_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
 
@@ -219,11 +227,16 @@ inline size_t bvh_lds_bytes(const cl2_renderer* r) {
 inline bool tree_in_lds(const cl2_renderer* r) { return r->bvh.lds_tris && r->bvh.n_nodes <= r->bvh.n_lds_nodes; }
 inline bool split_paths(const cl2_renderer* r) {
     if (r->traversal_mode == 1 || r->traversal_mode == 3) return false;
-    if (r->traversal_mode == 2 || r->traversal_mode == 4) return true;
+    if (r->traversal_mode == 2 || r->traversal_mode == 4 || r->traversal_mode == 5) return true;
     return !tree_in_lds(r);
 }
 inline bool split_conn(const cl2_renderer* r) {
     return r->traversal_mode >= 2 || (r->traversal_mode == 0 && !tree_in_lds(r));
+}
+// The exact 4-wide walk (bvh_wide.hpp) for the persistent traversal launches: mode 5 (per-level subpaths + connection
+// rays), never while counting (node-test tallies are defined by the binary walk).
+inline bool wide_walk(const cl2_renderer* r) {
+    return r->n_wide > 0 && !r->counting && r->traversal_mode == 5;
 }
 // Whole subpaths (light, then camera, all levels) in ONE persistent launch per sample (k_subpaths_persistent)
 // instead of a traversal + a bounce launch per level and kind: mode 4.  Measured at 1080p (ms per sample, serial order /
@@ -276,6 +289,32 @@ inline int persistent_grid_conn(const cl2_renderer* r) {
     return (r->pipe_active && e < 8) ? 256 * (8 - e) : persistent_grid();
 }
 
+// One persistent launch of the exact 4-wide walk + the (tiny) binary launch for the rays it left over (non-finite 1/d).
+// `stage` 0 = subpath stage, 1 = connection stage: each has its own left-over list and stack-overflow region, since the
+// two run side by side in the sample pipeline.
+template <class Source>
+int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* count, unsigned* work_counter, Source src, int is_conn) {
+    const int grid = stage == 0 ? persistent_grid_paths(r) : persistent_grid_conn(r);
+    WideView w = r->wide;
+    w.overflow = r->d_wide_ovf + (size_t)stage * persistent_grid() * BLOCK * WIDE_STACK_OVERFLOW;
+    w.leftover = r->d_leftover[stage];
+    w.leftover_count = r->d_leftover_count + stage;
+    HIP_TRY(r, hipMemsetAsync(w.leftover_count, 0, sizeof(unsigned), st));
+    const size_t lds = (size_t)WIDE_STACK_LDS * BLOCK * 8;
+    if (two_tris_per_step(r)) hipLaunchKernelGGL((k_traverse_wide<true, Source>), dim3(grid), dim3(BLOCK), lds, st, w, count, work_counter, src, r->d_stats, is_conn);
+    else hipLaunchKernelGGL((k_traverse_wide<false, Source>), dim3(grid), dim3(BLOCK), lds, st, w, count, work_counter, src, r->d_stats, is_conn);
+    HIP_TRY(r, hipGetLastError());
+    // left-over rays: the binary walk over the list (its own work counter: slot stage of d_leftover_count + 2)
+    Source rest = src;
+    rest.remap = w.leftover;
+    unsigned* work2 = r->d_leftover_count + 2 + stage;
+    HIP_TRY(r, hipMemsetAsync(work2, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL((k_traverse_persistent<false, false, Source>), dim3(64), dim3(BLOCK), bvh_lds_bytes(r), st, r->bvh, w.leftover_count,
+                       work2, rest, r->d_stats, -1);
+    HIP_TRY(r, hipGetLastError());
+    return CL2_OK;
+}
+
 // Subpath phase scratch (d_queue, d_qcount[0..6], d_work[0..6], d_hit, d_block_stats) is touched by this
 // phase only; the connection phase owns d_qcount[7] and d_work[7].
 int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set) {
@@ -294,7 +333,11 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
         unsigned* c_out = r->d_qcount + end;
         if (split) {
             Timed t(r, ST_TRAVERSE_PATHS, st);
-            PathRaySource src{q_in, pb.P0 + (size_t)first * B, pb.P1 + (size_t)first * B, r->d_hit};
+            PathRaySource src{q_in, pb.P0 + (size_t)first * B, pb.P1 + (size_t)first * B, r->d_hit, nullptr};
+            if (wide_walk(r)) {
+                TRY(launch_wide(r, st, 0, c_in, r->d_work + first, src, 0));
+                r->launches_tp++;
+            } else {
 #define CL2_PERSIST(CNT, TWO)                                                                                              \
             hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, PathRaySource>), dim3(persistent_grid_paths(r)), dim3(BLOCK), bvh_lds_bytes(r), \
                                st, r->bvh, c_in, r->d_work + first, src, r->d_stats, 0)
@@ -303,6 +346,7 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
 #undef CL2_PERSIST
             r->launches_tp++;
             HIP_TRY(r, hipGetLastError());
+            }
         }
         Timed t(r, split ? ST_BOUNCE : ST_TRAVERSE_PATHS, st);
 #define CL2_TRACE(CAM, CNT, EXT)                                                                                          \
@@ -371,13 +415,17 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
         if (split_conn(r)) {
             HIP_TRY(r, hipMemsetAsync(r->d_work + 7, 0, sizeof(unsigned), st));
             ConnRaySource src{r->d_ctag, lp.P0, cp.P0, r->d_chit[cs],
-                              V3{r->cam.focal_point[0], r->cam.focal_point[1], r->cam.focal_point[2]}, B};
+                              V3{r->cam.focal_point[0], r->cam.focal_point[1], r->cam.focal_point[2]}, B, nullptr};
+            if (wide_walk(r)) {
+                TRY(launch_wide(r, st, 1, r->d_qcount + 7, r->d_work + 7, src, 1));
+            } else {
 #define CL2_PERSIST(CNT, TWO)                                                                                             \
             hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, ConnRaySource>), dim3(persistent_grid_conn(r)), dim3(BLOCK), bvh_lds_bytes(r), \
                                st, r->bvh, r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1)
             if (two_tris_per_step(r)) { if (r->counting) CL2_PERSIST(true, true); else CL2_PERSIST(false, true); }
             else { if (r->counting) CL2_PERSIST(true, false); else CL2_PERSIST(false, false); }
 #undef CL2_PERSIST
+            }
         } else {
             // grid-stride over the (device-side) ray count; enough workgroups to fill 256 CUs several times over
             const int grid = std::min<size_t>(grid_for((size_t)B * 8), 256 * 32);
@@ -682,6 +730,61 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
         if (ltris[l].material < 0 || ltris[l].material >= n_mats) return fail(r, CL2_E_INVALID, "light material index out of range");
     }
 
+    // ---- 4-wide collapse for the exact wide walk (bvh_wide.hpp).  Conditions: the root is an inner box, every box
+    // nests its children exactly (what the exactness argument rests on; true for trees that np_flatten_bvh or either
+    // native builder made, not guaranteed for hand-made Box[] arrays) and no leaf exceeds one record. ----
+    std::vector<float4> h_wide;
+    int n_wide = 0;
+    {
+        bool ok = n_boxes >= 3 && boxes[0].right == 0;
+        auto inside = [&](const BoxRec& c, const BoxRec& p) {
+            for (int k = 0; k < 3; k++) if (!(c.min[k] >= p.min[k] && c.max[k] <= p.max[k])) return false;
+            return true;
+        };
+        for (int i = 0; i < n_boxes && ok; i++) {
+            const BoxRec& b = boxes[i];
+            if (b.right == 0) ok = inside(boxes[b.left], b) && inside(boxes[b.left + 1], b);
+            else ok = (b.right - b.left) <= LEAF_PACK_MAX;
+        }
+        if (ok) {
+            // slots of reference box x in its visit order: child left+1 first, each inner child replaced by its children
+            auto slots_of = [&](int x, int* out) {
+                int n = 0;
+                for (int c : {boxes[x].left + 1, boxes[x].left}) {
+                    if (boxes[c].right != 0) out[n++] = c;
+                    else { out[n++] = boxes[c].left + 1; out[n++] = boxes[c].left; }
+                }
+                return n;
+            };
+            std::vector<int> wide_of(n_boxes, -1), order;
+            order.push_back(0); wide_of[0] = 0;
+            for (size_t h = 0; h < order.size(); h++) {
+                int sl[4];
+                const int n = slots_of(order[h], sl);
+                for (int k = 0; k < n; k++)
+                    if (boxes[sl[k]].right == 0) { wide_of[sl[k]] = (int)order.size(); order.push_back(sl[k]); }
+            }
+            n_wide = (int)order.size();
+            h_wide.assign((size_t)8 * n_wide, make_float4(0, 0, 0, 0));
+            for (int wn = 0; wn < n_wide; wn++) {
+                int sl[4];
+                const int n = slots_of(order[wn], sl);
+                float v[6][4];
+                int ref[4];
+                for (int k = 0; k < 4; k++) {
+                    ref[k] = WIDE_EMPTY;
+                    for (int c = 0; c < 6; c++) v[c][k] = 0.0f;
+                    if (k >= n) continue;
+                    const BoxRec& b = boxes[sl[k]];
+                    for (int c = 0; c < 3; c++) { v[c][k] = b.min[c]; v[3 + c][k] = b.max[c]; }
+                    ref[k] = b.right == 0 ? wide_of[sl[k]] : ~((b.left << 4) | (b.right - b.left - 1));
+                }
+                for (int c = 0; c < 6; c++) h_wide[(size_t)8 * wn + c] = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+                h_wide[(size_t)8 * wn + 6] = make_float4(as_f_int(ref[0]), as_f_int(ref[1]), as_f_int(ref[2]), as_f_int(ref[3]));
+            }
+        }
+    }
+
     // ---- repack ----
     std::vector<float4> h_nodes(2 * (size_t)n_records), h_tris(3 * (size_t)n_tris), h_shade(4 * (size_t)n_tris),
         h_ltris(5 * (size_t)light_count);
@@ -757,6 +860,21 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     HIP_TRY(r, hipMemcpy(r->d_light_areas, light_areas, (size_t)light_count * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(r, hipMemcpy(r->d_light_tri_index, light_tri_index, (size_t)light_count * sizeof(int), hipMemcpyHostToDevice));
 
+    dev_free(r, r->d_wide);
+    r->n_wide = 0;
+    if (n_wide > 0) {
+        TRY(dev_alloc(r, &r->d_wide, h_wide.size()));
+        HIP_TRY(r, hipMemcpy(r->d_wide, h_wide.data(), h_wide.size() * sizeof(float4), hipMemcpyHostToDevice));
+        const size_t lanes = (size_t)persistent_grid() * BLOCK;
+        if (!r->d_wide_ovf) TRY(dev_alloc(r, &r->d_wide_ovf, 2 * lanes * WIDE_STACK_OVERFLOW));
+        if (!r->d_leftover[0]) TRY(dev_alloc(r, &r->d_leftover[0], (size_t)r->B));
+        if (!r->d_leftover[1]) TRY(dev_alloc(r, &r->d_leftover[1], (size_t)CONN_SLOTS * r->B));
+        if (!r->d_leftover_count) { TRY(dev_alloc(r, &r->d_leftover_count, (size_t)4)); HIP_TRY(r, hipMemset(r->d_leftover_count, 0, 4 * sizeof(unsigned))); }
+        r->wide.nodes = r->d_wide; r->wide.tris = r->d_tris;
+        r->wide.root_lo = make_float4(boxes[0].min[0], boxes[0].min[1], boxes[0].min[2], 0.0f);
+        r->wide.root_hi = make_float4(boxes[0].max[0], boxes[0].max[1], boxes[0].max[2], 0.0f);
+        r->n_wide = n_wide;
+    }
     r->bvh.nodes = r->d_nodes; r->bvh.tris = r->d_tris;
     r->bvh.n_nodes = n_records; r->bvh.n_tris = n_tris;
     r->bvh.n_lds_nodes = std::min(n_records, LDS_NODE_CAP);
@@ -1127,7 +1245,7 @@ int cl2_probe_bounce(cl2_renderer* r, int from_camera, const float* in, size_t n
 }
 int cl2_set_traversal_mode(cl2_renderer* r, int mode) {
     if (!r) return CL2_E_INVALID;
-    if (mode < 0 || mode > 4) return fail(r, CL2_E_INVALID, "traversal mode must be 0 (auto), 1 (fused), 2 (persistent, per level), 3 (fused subpaths, persistent connection rays) or 4 (persistent whole subpaths)");
+    if (mode < 0 || mode > 5) return fail(r, CL2_E_INVALID, "traversal mode must be 0 (auto), 1 (fused), 2 (persistent, per level), 3 (fused subpaths, persistent connection rays), 4 (persistent whole subpaths) or 5 (persistent, exact 4-wide walk)");
     r->traversal_mode = mode;
     r->paths_share = 0;
     return CL2_OK;

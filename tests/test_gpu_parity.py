@@ -155,7 +155,7 @@ def test_levels_per_launch_is_a_pure_performance_knob(levels, glass_scene, oracl
         r.set_levels_per_launch(7)
 
 
-@pytest.mark.parametrize("mode", [2, 4])
+@pytest.mark.parametrize("mode", [2, 4, 5])
 @pytest.mark.parametrize("flags", [0, 1 << 12, (4 << 13) | (1 << 16) | (1 << 24), (7 << 13) | (64 << 16) | (100 << 24) | (1 << 12)])
 @pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
 def test_persistent_traversal_mode_is_equivalent(scene_name, flags, mode, request, oracle_mod):
@@ -466,7 +466,7 @@ def test_movie_cli_writes_turntable_frames(tmp_path):
     assert not np.array_equal(frames[0], frames[1])        # the camera moved
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
 def test_sample_pipeline_is_a_pure_performance_knob(mode, glass_scene, oracle_mod):
     """run_samples as a pipeline over samples (later stages of sample i on their own streams beside
     the subpath stage of the next samples; 2 and 3 stages) == serial order == oracle: seeds, last
