@@ -39,15 +39,21 @@ struct WideView {
     int2* overflow;            // [lanes of the launch][WIDE_STACK_OVERFLOW]
     unsigned* leftover;        // queue positions of rays with a non-finite 1/d ...
     unsigned* leftover_count;  // ... and how many
+    int stack_lds;             // stack entries kept in LDS per lane (<= WIDE_STACK_LDS)
+    int n_lds_nodes;           // wide nodes [0, n_lds_nodes) (breadth-first numbering: the top of the tree) staged in LDS
 };
 
 template <bool COUNT, bool TWO_TRIS, class Source>
 __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, unsigned n, unsigned* work_counter, const Source& src,
                                                          unsigned& n_box, unsigned& n_tri) {
     extern __shared__ float4 cl2_tree_lds[];
-    int* s_ref = reinterpret_cast<int*>(cl2_tree_lds);                                  // [WIDE_STACK_LDS][blockDim.x]
-    float* s_tmin = reinterpret_cast<float*>(cl2_tree_lds) + WIDE_STACK_LDS * blockDim.x;
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int S = w.stack_lds;
+    float4* s_nodes = cl2_tree_lds;                                                     // [8 * n_lds_nodes]
+    int* s_ref = reinterpret_cast<int*>(cl2_tree_lds + 8 * w.n_lds_nodes);              // [S][blockDim.x]
+    float* s_tmin = reinterpret_cast<float*>(s_ref) + S * nt;
+    for (int i = tid; i < 8 * w.n_lds_nodes; i += nt) s_nodes[i] = w.nodes[i];
+    __syncthreads();
     int2* ovf = w.overflow + ((size_t)blockIdx.x * nt + tid) * WIDE_STACK_OVERFLOW;
     const int lane = tid & 63;
     const unsigned waves = gridDim.x * (blockDim.x >> 6);
@@ -63,8 +69,8 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, unsi
     unsigned key = 0;
 
     auto push = [&](int ref, float tmin) {
-        if (sp < WIDE_STACK_LDS) { s_ref[sp * nt + tid] = ref; s_tmin[sp * nt + tid] = tmin; }
-        else ovf[sp - WIDE_STACK_LDS] = make_int2(ref, __float_as_int(tmin));
+        if (sp < S) { s_ref[sp * nt + tid] = ref; s_tmin[sp * nt + tid] = tmin; }
+        else ovf[sp - S] = make_int2(ref, __float_as_int(tmin));
         sp++;
     };
     // next work item of the lane: pops until an entry still passes `tmin < best_t` (the reference's test of that box
@@ -73,8 +79,8 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, unsi
         while (sp > 0 && cur < 0 && tri_i >= tri_end) {
             sp--;
             int ref; float tmin;
-            if (sp < WIDE_STACK_LDS) { ref = s_ref[sp * nt + tid]; tmin = s_tmin[sp * nt + tid]; }
-            else { const int2 e = ovf[sp - WIDE_STACK_LDS]; ref = e.x; tmin = __int_as_float(e.y); }
+            if (sp < S) { ref = s_ref[sp * nt + tid]; tmin = s_tmin[sp * nt + tid]; }
+            else { const int2 e = ovf[sp - S]; ref = e.x; tmin = __int_as_float(e.y); }
             if (!(tmin < best.t)) continue;
             if (ref >= 0) cur = ref;
             else { const int info = ~ref; tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
@@ -125,7 +131,7 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, unsi
             pop_next();                                                     // lanes that finished a leaf in the previous pass
             if (cur >= 0) {
                 // one wide node: the slab tests of up to four boxes, in the reference's visit order (slot 0 first)
-                const float4* nd = w.nodes + (size_t)8 * cur;
+                const float4* nd = cur < w.n_lds_nodes ? s_nodes + 8 * cur : w.nodes + (size_t)8 * cur;
                 const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
                 const float4 rf = nd[6];
                 cur = -1;

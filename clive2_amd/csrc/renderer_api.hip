@@ -224,19 +224,39 @@ int launch_generate_both(cl2_renderer* r, hipStream_t st, const PathBufs* set) {
 inline size_t bvh_lds_bytes(const cl2_renderer* r) {
     return ((size_t)2 * r->bvh.n_lds_nodes + (r->bvh.lds_tris ? (size_t)3 * r->bvh.n_tris : 0)) * sizeof(float4);
 }
+// The cooperative walk keeps 13 KB of staging per workgroup in LDS; its node window is cut to what still lets eight
+// workgroups share a CU (debug_flags bits 16-19: window in units of 64 records, 0 = default 2 = 128 records).
+inline BvhView coop_view(const cl2_renderer* r) {
+    BvhView v = r->bvh;
+    const int units = (r->debug_flags >> 16) & 0xF;
+    v.n_lds_nodes = std::min(v.n_lds_nodes, 64 * (units ? units : 2));
+    return v;
+}
+inline size_t coop_lds_bytes(const cl2_renderer* r) {
+    const BvhView v = coop_view(r);
+    return ((size_t)2 * v.n_lds_nodes + (v.lds_tris ? (size_t)3 * v.n_tris : 0)) * sizeof(float4);
+}
 inline bool tree_in_lds(const cl2_renderer* r) { return r->bvh.lds_tris && r->bvh.n_nodes <= r->bvh.n_lds_nodes; }
 inline bool split_paths(const cl2_renderer* r) {
     if (r->traversal_mode == 1 || r->traversal_mode == 3) return false;
-    if (r->traversal_mode == 2 || r->traversal_mode == 4 || r->traversal_mode == 5) return true;
+    if (r->traversal_mode == 2 || r->traversal_mode >= 4) return true;
     return !tree_in_lds(r);
 }
 inline bool split_conn(const cl2_renderer* r) {
     return r->traversal_mode >= 2 || (r->traversal_mode == 0 && !tree_in_lds(r));
 }
-// The exact 4-wide walk (bvh_wide.hpp) for the persistent traversal launches: mode 5 (per-level subpaths + connection
-// rays), never while counting (node-test tallies are defined by the binary walk).
+// The exact 4-wide walk (bvh_wide.hpp) for the connection-ray launch: mode 5, and the automatic choice for trees that
+// are read through the caches (same 16 MB limit as the two-triangle step): connection launch 5.78 -> 4.89 ms on the
+// glass scene, 6.98 -> 6.02 ms on the blob (sample pipeline: 13.7 -> 12.5 ms, 16.6 -> 15.4 ms).  A 155 MB tree walks
+// slower this way (15.7 -> 18.6 ms: a wide node moves a whole 128-byte line per visit, used or not, and that walk is
+// bound by the bytes that miss L2), so it keeps the binary walk.  Never while counting: the node-test tallies are
+// defined by the binary walk.  The per-level subpath launches (tail-bound, 2 M rays each) gain nothing from it
+// (debug_flags bit 3 sends them through it anyway, for tests).
 inline bool wide_walk(const cl2_renderer* r) {
-    return r->n_wide > 0 && !r->counting && r->traversal_mode == 5;
+    if (r->n_wide <= 0 || r->counting) return false;
+    if (r->traversal_mode == 5) return true;
+    const size_t bytes = (size_t)r->bvh.n_nodes * 32 + (size_t)r->bvh.n_tris * 48;
+    return r->traversal_mode == 0 && !tree_in_lds(r) && bytes <= ((size_t)16 << 20);
 }
 // Whole subpaths (light, then camera, all levels) in ONE persistent launch per sample (k_subpaths_persistent)
 // instead of a traversal + a bounce launch per level and kind: mode 4.  Measured at 1080p (ms per sample, serial order /
@@ -300,7 +320,12 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
     w.leftover = r->d_leftover[stage];
     w.leftover_count = r->d_leftover_count + stage;
     HIP_TRY(r, hipMemsetAsync(w.leftover_count, 0, sizeof(unsigned), st));
-    const size_t lds = (size_t)WIDE_STACK_LDS * BLOCK * 8;
+    // LDS per workgroup: per-lane stack (8 B per entry and lane) + the top of the tree (128 B per wide node); experiment
+    // switches: debug_flags bits 16-19 stack entries (0 = default), bits 20-23 window in units of 32 wide nodes
+    const int sflag = (r->debug_flags >> 16) & 0xF, wflag = (r->debug_flags >> 20) & 0xF;
+    w.stack_lds = sflag ? std::min(sflag, WIDE_STACK_LDS) : 4;
+    w.n_lds_nodes = std::min(r->n_wide, 32 * (wflag ? wflag : 2));
+    const size_t lds = (size_t)w.stack_lds * BLOCK * 8 + (size_t)w.n_lds_nodes * 128;
     if (two_tris_per_step(r)) hipLaunchKernelGGL((k_traverse_wide<true, Source>), dim3(grid), dim3(BLOCK), lds, st, w, count, work_counter, src, r->d_stats, is_conn);
     else hipLaunchKernelGGL((k_traverse_wide<false, Source>), dim3(grid), dim3(BLOCK), lds, st, w, count, work_counter, src, r->d_stats, is_conn);
     HIP_TRY(r, hipGetLastError());
@@ -334,13 +359,19 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
         if (split) {
             Timed t(r, ST_TRAVERSE_PATHS, st);
             PathRaySource src{q_in, pb.P0 + (size_t)first * B, pb.P1 + (size_t)first * B, r->d_hit, nullptr};
-            if (wide_walk(r)) {
+            if (wide_walk(r) && ((r->debug_flags >> 3) & 1)) {      // experiment switch: the per-level subpath launches too
                 TRY(launch_wide(r, st, 0, c_in, r->d_work + first, src, 0));
                 r->launches_tp++;
             } else {
 #define CL2_PERSIST(CNT, TWO)                                                                                              \
-            hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, PathRaySource>), dim3(persistent_grid_paths(r)), dim3(BLOCK), bvh_lds_bytes(r), \
-                               st, r->bvh, c_in, r->d_work + first, src, r->d_stats, 0)
+            do {                                                                                                           \
+                if (r->traversal_mode == 6)                                                                                \
+                    hipLaunchKernelGGL((k_traverse_coop<CNT, TWO, PathRaySource>), dim3(persistent_grid_paths(r)), dim3(BLOCK), coop_lds_bytes(r), \
+                                       st, coop_view(r), c_in, r->d_work + first, src, r->d_stats, 0);                      \
+                else                                                                                                       \
+                    hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, PathRaySource>), dim3(persistent_grid_paths(r)), dim3(BLOCK), bvh_lds_bytes(r), \
+                                       st, r->bvh, c_in, r->d_work + first, src, r->d_stats, 0);                           \
+            } while (0)
             if (two_tris_per_step(r)) { if (r->counting) CL2_PERSIST(true, true); else CL2_PERSIST(false, true); }
             else { if (r->counting) CL2_PERSIST(true, false); else CL2_PERSIST(false, false); }
 #undef CL2_PERSIST
@@ -420,8 +451,14 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
                 TRY(launch_wide(r, st, 1, r->d_qcount + 7, r->d_work + 7, src, 1));
             } else {
 #define CL2_PERSIST(CNT, TWO)                                                                                             \
-            hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, ConnRaySource>), dim3(persistent_grid_conn(r)), dim3(BLOCK), bvh_lds_bytes(r), \
-                               st, r->bvh, r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1)
+            do {                                                                                                          \
+                if (r->traversal_mode == 6)                                                                               \
+                    hipLaunchKernelGGL((k_traverse_coop<CNT, TWO, ConnRaySource>), dim3(persistent_grid_conn(r)), dim3(BLOCK), coop_lds_bytes(r), \
+                                       st, coop_view(r), r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1);              \
+                else                                                                                                      \
+                    hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, ConnRaySource>), dim3(persistent_grid_conn(r)), dim3(BLOCK), bvh_lds_bytes(r), \
+                                       st, r->bvh, r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1);                   \
+            } while (0)
             if (two_tris_per_step(r)) { if (r->counting) CL2_PERSIST(true, true); else CL2_PERSIST(false, true); }
             else { if (r->counting) CL2_PERSIST(true, false); else CL2_PERSIST(false, false); }
 #undef CL2_PERSIST
@@ -1245,7 +1282,7 @@ int cl2_probe_bounce(cl2_renderer* r, int from_camera, const float* in, size_t n
 }
 int cl2_set_traversal_mode(cl2_renderer* r, int mode) {
     if (!r) return CL2_E_INVALID;
-    if (mode < 0 || mode > 5) return fail(r, CL2_E_INVALID, "traversal mode must be 0 (auto), 1 (fused), 2 (persistent, per level), 3 (fused subpaths, persistent connection rays), 4 (persistent whole subpaths) or 5 (persistent, exact 4-wide walk)");
+    if (mode < 0 || mode > 6) return fail(r, CL2_E_INVALID, "traversal mode must be 0 (auto), 1 (fused), 2 (persistent, per level), 3 (fused subpaths, persistent connection rays), 4 (persistent whole subpaths) 5 (persistent, exact 4-wide walk) or 6 (persistent, cooperative triangle fetches)");
     r->traversal_mode = mode;
     r->paths_share = 0;
     return CL2_OK;
@@ -1265,6 +1302,8 @@ int cl2_query_organisation(cl2_renderer* r, cl2_organisation* out) {
     out->levels_per_launch = split_paths(r) ? 1 : effective_levels(r);
     out->paths_share = r->paths_share;
     out->pipeline_stages = pipeline_stages(r);
+    out->wide_nodes = r->n_wide;
+    out->wide_connections = (wide_walk(r) && split_conn(r)) ? 1 : 0;
     out->tree_bytes = (int64_t)r->bvh.n_nodes * 32 + (int64_t)r->bvh.n_tris * 48;
     return CL2_OK;
 }
@@ -1391,7 +1430,27 @@ int cl2_probe_traverse(cl2_renderer* r, const void* rays_v, size_t n_rays, int32
                   hipMemcpy(d_n, &n, sizeof n, hipMemcpyHostToDevice) == hipSuccess;
         if (!ok) rc = fail(r, CL2_E_HIP, "probe upload failed");
     }
-    if (rc == CL2_OK) {
+    if (rc == CL2_OK && r->traversal_mode >= 5 && r->n_wide > 0 && !r->counting) {
+        // the probe through the persistent organisations under test: the exact 4-wide walk with its left-over list (mode 5:
+        // rays with a non-finite 1/d go to the binary walk) or the cooperative walk (mode 6)
+        unsigned* d_left = nullptr;
+        rc = dev_alloc(r, &d_left, n_rays);
+        if (rc == CL2_OK && hipMemsetAsync(r->d_work, 0, sizeof(unsigned), r->stream) != hipSuccess) rc = fail(r, CL2_E_HIP, "probe memset failed");
+        if (rc == CL2_OK) {
+            PathRaySource src{nullptr, d_o, d_d, d_h, nullptr};
+            if (r->traversal_mode == 5) {
+                unsigned* keep = r->d_leftover[0];
+                r->d_leftover[0] = d_left;
+                rc = launch_wide(r, r->stream, 0, d_n, r->d_work, src, 0);
+                r->d_leftover[0] = keep;
+            } else {
+                hipLaunchKernelGGL((k_traverse_coop<false, true, PathRaySource>), dim3(persistent_grid()), dim3(BLOCK), coop_lds_bytes(r), r->stream,
+                                   coop_view(r), d_n, r->d_work, src, r->d_stats, 0);
+            }
+            if (rc == CL2_OK) rc = drain(r);
+        }
+        dev_free(r, d_left);
+    } else if (rc == CL2_OK) {
         if (r->counting)
             hipLaunchKernelGGL(k_traverse_paths<true>, dim3(grid_for(n_rays)), dim3(BLOCK), bvh_lds_bytes(r), r->stream, r->bvh, (const int*)nullptr, d_n, d_o, d_d, d_h, r->d_stats);
         else

@@ -124,9 +124,11 @@ int cl2_set_levels_per_launch(cl2_renderer* r, int levels);
  * bounce launch per level (rays of very different cost: large trees), 3 = subpaths as in 1, connection
  * rays as in 2 (mid-size trees in serial order: no per-level launch tails), 4 = connection rays as in 2 and
  * both subpaths of a pixel -- light, then camera, all levels -- walked by one lane of ONE persistent launch
- * per sample, the bounces batched per wave (one launch tail instead of 24), 0 (default) = 1 for LDS-resident
- * trees, otherwise 2 while the sample pipeline runs and 4 in serial order.  Results are identical for every
- * setting. */
+ * per sample, the bounces batched per wave (one launch tail instead of 24), 5 = as 2 with the connection rays walked
+ * over an exact 4-wide collapse of the tree (half the dependent fetches, same decisions: csrc/bvh_wide.hpp), 6 = as 2
+ * with triangles fetched cooperatively by the wave (measured slower; kept as an organisation under test), 0 (default)
+ * = 1 for LDS-resident trees, otherwise 2 while the sample pipeline runs and 4 in serial order, with the 4-wide walk
+ * for the connection rays when the tree is at most 16 MB.  Results are identical for every setting. */
 int cl2_set_traversal_mode(cl2_renderer* r, int mode);
 /* Sample pipeline of cl2_run_samples.  The seed buffer is the only state one sample hands to the next
  * (src/renderer.py:86-87) and only the subpath stage (K1, K2, K3) touches it, so later stages of
@@ -189,6 +191,8 @@ typedef struct {
     int32_t levels_per_launch;      /* effective subpath levels per launch */
     int32_t paths_share;            /* tuned share of the wave slots for the subpath stage, eighths (0 = not tuned yet, 9 = serial order won) */
     int32_t pipeline_stages;        /* effective setting of cl2_set_pipelining */
+    int32_t wide_connections;       /* connection rays walk the exact 4-wide collapse of the tree (csrc/bvh_wide.hpp) */
+    int32_t wide_nodes;             /* nodes of that collapse (0: not available: hand-made boxes that do not nest, leaves above 16 triangles) */
     int32_t pad;
     int64_t tree_bytes;             /* 32 B per record + 48 B per intersection triangle */
 } cl2_organisation;
@@ -204,7 +208,10 @@ int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
  * kernel (2 / 4: register budget; 7: one wave per camera vertex -- only in the test variant of the library,
  * libclive2_amd_test.so, built with -DCL2_TEST_VARIANT); bits 8-10 eighths of the wave slots given to the subpath stage while the sample
  * pipeline runs on a large scene (0 = tuned); bit 12 inverts the one/two-triangles-per-step choice of
- * the persistent walk; whole-subpath launch (mode 4): bits 13-15 register budget as waves per SIMD (4, 5, 6;
+ * the persistent walk; bit 3 sends the per-level subpath launches through the 4-wide walk too; 4-wide walk:
+ * bits 16-19 stack entries per lane in LDS (0 = default 4), bits 20-23 LDS window in units of 32 wide nodes
+ * (0 = default 2); cooperative walk (mode 6): bits 16-19 node window in units of 64 records; whole-subpath launch
+ * (mode 4): bits 13-15 register budget as waves per SIMD (4, 5, 6;
  * 7 = 8; 0 = default 5), bits 16-22 lanes gathered before a wave runs its bounce phase (0 = default 32),
  * bits 24-30 steps a finished lane waits at most (0 = default 48). */
 int cl2_set_debug_flags(cl2_renderer* r, int flags);

@@ -222,6 +222,18 @@ def _exact_vs_oracle(scene, oracle_mod, samples=2):
     assert c["rays"] == o.rays_traced
     # the oracle counts node / triangle tests of the reference's stack walk; the stackless walk makes the same ones
     assert c["box_tests"] == int(o.counters["box_tests"][0]) and c["tri_tests"] == int(o.counters["tri_tests"][0])
+    # the next sample(s) without the counters: the organisation a render uses (node-test tallies are defined by the binary
+    # walk, so counting switches the 4-wide walk of the connection rays off) -- stage by stage once more, then run_samples
+    r.set_counting(False)
+    for x in (r, o):
+        x.make_light_rays(); x.make_camera_rays(); x.trace_light_rays(); x.trace_camera_rays()
+    for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
+        assert r.export_paths(which).tobytes() == ref.tobytes()
+    for x in (r, o):
+        x.join_paths(); x.finalize_samples(); x.gather_light_image(); x.process_images()
+    agg = r.export_aggregators()
+    assert agg["total_contribution"].tobytes() == o.weight_aggregators["total_contribution"].tobytes()
+    assert agg["contrib_weight_sum"].tobytes() == o.weight_aggregators["contrib_weight_sum"].tobytes()
     r.run_samples(samples - 1)
     for _ in range(samples - 1):
         o.run_sample()
@@ -264,6 +276,7 @@ def test_config4_real_size_vs_oracle(blob_real, oracle_mod):
     org = r.organisation()
     assert not org["tree_in_lds"] and org["persistent_subpaths"] and org["persistent_connections"]
     assert org["two_tris_per_step"] == 1                      # 27,947 x 32 B + 81,936 x 48 B = 4.8 MB <= 16 MB
+    assert org["wide_connections"] == 1 and org["wide_nodes"] > 5000   # connection rays: the exact 4-wide walk
     assert org["n_records"] > 20000 and org["n_lds_records"] == 512 and 0 < org["n_top_renumbered"] <= 512
     assert 12 < c["box_tests"] / c["counted_rays"] < 22       # N_node 16.3 at 1080p
 
@@ -283,13 +296,14 @@ def test_config5_real_size_vs_oracle(interior_real, oracle_mod):
     org = r.organisation()
     assert not org["tree_in_lds"] and org["persistent_subpaths"] and org["persistent_connections"]
     assert org["two_tris_per_step"] == 0 and org["tree_bytes"] > (16 << 20)     # one triangle per step above 16 MB
+    assert org["wide_connections"] == 0 and org["wide_nodes"] > 50000            # available, but the binary walk is faster here
     assert org["n_records"] > 300000 and org["n_lds_records"] == 512 and 0 < org["n_top_renumbered"] <= 512
     assert 50 < c["box_tests"] / c["counted_rays"] < 65      # N_node 57.6 at 1080p
     # both forms of the persistent step and the one-ray-per-lane organisation give the same subpaths
     from clive2_amd.renderer import Renderer, make_seeds
     seeds = make_seeds(96 * 54)
     ref = None
-    for mode, flags in ((0, 1 << 12), (1, 0)):
+    for mode, flags in ((0, 1 << 12), (1, 0), (5, 8), (6, 0)):
         x = Renderer(interior_real, seeds=seeds)
         x.set_traversal_mode(mode); x.set_debug_flags(flags)
         x.make_light_rays(); x.make_camera_rays(); x.trace_light_rays(); x.trace_camera_rays()
