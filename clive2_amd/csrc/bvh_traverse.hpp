@@ -42,7 +42,6 @@ struct BvhView {
 constexpr int LDS_NODE_CAP = 512;   // records in the LDS window: at most 512 * 32 B = 16 KB
 constexpr int LDS_TRI_CAP = 512;    // triangles staged in LDS when the whole scene has no more: at most 512 * 48 B = 24 KB
 constexpr int LEAF_PACK_MAX = 16;   // triangles per leaf record
-constexpr int WAVES_PER_BLOCK_MAX = 4;   // the traversal kernels run 256-thread workgroups
 
 // The staged part of the tree lives in DYNAMIC shared memory sized by the scene (bvh_lds_bytes on the
 // host): the Cornell box takes 1 KB, a 500-triangle scene 40 KB -- one kernel serves both without the
@@ -318,142 +317,4 @@ __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhVi
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// The same walk with COOPERATIVE triangle fetches.
-//
-// What bounds the persistent walk on trees that live in the caches is neither VALU issue nor DRAM but the rate at
-// which a CU's L1 can look up cache lines for scattered loads: one 128-byte line per cycle whatever the bytes used
-// (tools/l1_gather_rate.hip: 0.92 distinct lines per cycle per CU from L1, 0.43 from L2, 0.09 past L2; lanes that hit
-// the same line in one instruction are served together).  A lane that fetches "its" triangle issues three 16-byte
-// loads = three line look-ups, two thirds of all look-ups of the walk (PMC: 3.3 G lane-loads in the 5.7 ms connection
-// launch of the glass scene = 0.94 per cycle per CU: the walk sits on that limit).  Here the lanes that need a
-// triangle post its index in a per-wave LDS list; then ALL lanes fetch: lane 3q+p loads float4 number p of request q,
-// so one load instruction carries 21 whole triangles and touches each record's line once (1.4 lines per 48-byte
-// record instead of 3 look-ups); the records are staged in LDS and the owners read theirs back.  Same triangles, same
-// tests, same order per ray: identical results.
-constexpr int COOP_STAGE_F4 = 3 * 64;       // staging per wave: 64 triangles x 3 float4 (3 KB) + 64 indices
-
-struct CoopLds {
-    float4 stage[WAVES_PER_BLOCK_MAX][COOP_STAGE_F4];
-    int req[WAVES_PER_BLOCK_MAX][64];
-};
-
-template <bool COUNT, bool TWO_TRIS, class Source>
-__device__ __forceinline__ void traverse_persistent_coop(const BvhLds& s, const BvhView& b, CoopLds& cl, unsigned n, unsigned* work_counter,
-                                                         const Source& src, unsigned& n_box, unsigned& n_tri) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4* stage = cl.stage[wave];
-    int* req = cl.req[wave];
-    const unsigned waves = gridDim.x * (blockDim.x >> 6);
-    unsigned chunk = n / (waves * 4u);
-    chunk = chunk < 64u ? 64u : (chunk > (unsigned)RAY_CHUNK_MAX ? (unsigned)RAY_CHUNK_MAX : chunk);
-    unsigned w_next = 0, w_end = 0;
-    bool dry = false;
-    bool active = false, fast = true;
-    V3 o = v3(0, 0, 0), d = o, inv = o;
-    Hit best{-1, __builtin_inff(), 0.0f, 0.0f};
-    const int n_nodes = b.n_nodes;
-    int node = n_nodes, tri_i = 0, tri_end = 0;
-    unsigned key = 0;
-    const unsigned long long below = (1ull << lane) - 1ull;
-
-    // every lane calls it (wave-uniform control flow); lanes with `want` get triangle `index` in a0..a2
-    auto coop_fetch = [&](bool want, int index, float4& a0, float4& a1, float4& a2) {
-        const unsigned long long wm = __ballot(want);
-        const int n_req = __popcll(wm), slot = __popcll(wm & below);
-        if (want) req[slot] = index;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int base = 0; base < 3 * n_req; base += 64) {                 // at most three rounds
-            const int item = base + lane;
-            if (item < 3 * n_req) {
-                const int q = item / 3, part = item - 3 * q;
-                stage[item] = b.tris[3 * req[q] + part];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (want) { a0 = stage[3 * slot]; a1 = stage[3 * slot + 1]; a2 = stage[3 * slot + 2]; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    while (true) {
-        unsigned long long idle = __ballot(!active);
-        while (idle && !dry) {
-            if (w_next >= w_end) {
-                unsigned base = 0;
-                if (lane == 0) base = atomicAdd(work_counter, chunk);
-                base = __shfl(base, 0);
-                if (base >= n) { dry = true; break; }
-                w_next = base;
-                w_end = base + chunk < n ? base + chunk : n;
-            }
-            const unsigned avail = w_end - w_next;
-            const unsigned rank = __popcll(idle & below);
-            const bool take = !active && rank < avail;
-            if (take) {
-                key = w_next + rank;
-                src.load(key, o, d);
-                inv = rcp3(d);
-                fast = finite3(inv);
-                best = Hit{-1, __builtin_inff(), 0.0f, 0.0f};
-                node = 0; tri_i = 0; tri_end = 0;
-                active = true;
-            }
-            const unsigned taken = __popcll(idle) < avail ? __popcll(idle) : avail;
-            w_next += taken;
-            idle = __ballot(!active);
-        }
-        if (!__any(active)) break;
-
-        const bool all_fast = __all(!active || fast);
-        if (active && tri_i >= tri_end && node < n_nodes) {
-            float4 lo, hi;
-            if (node < b.n_lds_nodes) { lo = s.nodes[2 * node]; hi = s.nodes[2 * node + 1]; }
-            else { lo = b.nodes[2 * node]; hi = b.nodes[2 * node + 1]; }
-            const int next = __float_as_int(lo.w);
-            if (COUNT) n_box++;
-            const float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
-            const float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
-            float tmin, tmax;
-            if (all_fast) {
-                tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
-                                       __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
-                tmax = __builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
-            } else {
-                tmin = max_msl(max_msl(min_msl(t0x, t1x), min_msl(t0y, t1y)), max_msl(min_msl(t0z, t1z), 0.0f));
-                tmax = min_msl(min_msl(max_msl(t0x, t1x), max_msl(t0y, t1y)), min_msl(max_msl(t0z, t1z), __builtin_inff()));
-            }
-            node = next;
-            if (tmin <= tmax && tmin < best.t) {
-                const int info = __float_as_int(hi.w);
-                if (info < 0) node = ~info;
-                else { tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
-            }
-        }
-        // triangles: one cooperative fetch + test per lane, a second one for lanes with another triangle pending
-#pragma unroll
-        for (int round = 0; round < (TWO_TRIS ? 2 : 1); round++) {
-            const bool want = active && tri_i < tri_end;
-            if (!__any(want)) break;
-            float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0;
-            coop_fetch(want, tri_i, a0, a1, a2);
-            if (want) {
-                if (COUNT) n_tri++;
-                tri_test(o, d, a0, a1, a2, tri_i, best);
-                tri_i++;
-            }
-        }
-        if (active && tri_i >= tri_end && node >= n_nodes) {
-            src.store(key, best);
-            active = false;
-        }
-    }
-}
-
 }  // namespace cl2
-

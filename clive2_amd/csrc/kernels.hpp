@@ -282,33 +282,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(78))) void k_
     }
 }
 
-// The binary walk with cooperative triangle fetches (traverse_persistent_coop): traversal mode 6.
-template <bool COUNT, bool TWO_TRIS, class Source>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(78))) void k_traverse_coop(
-        BvhView bvh, const unsigned* __restrict__ count, unsigned* __restrict__ work_counter, Source src, Stats* stats, int is_conn) {
-    BvhLds lds{nullptr, nullptr};
-    __shared__ CoopLds coop;
-    stage_bvh(lds, bvh);
-    const unsigned n = *count;
-    unsigned nb = 0, nt = 0;
-    traverse_persistent_coop<COUNT, TWO_TRIS>(lds, bvh, coop, n, work_counter, src, nb, nt);
-    if (COUNT) {
-        for (int off = 32; off > 0; off >>= 1) { nb += __shfl_down(nb, off); nt += __shfl_down(nt, off); }
-        if (lane_id() == 0) {
-            atomicAdd(&stats->box_tests, (unsigned long long)nb);
-            atomicAdd(&stats->tri_tests, (unsigned long long)nt);
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        atomicAdd(&stats->rays, (unsigned long long)n);
-        if (is_conn > 0) atomicAdd(&stats->conn_rays, (unsigned long long)n);
-        if (COUNT) atomicAdd(&stats->counted_rays, (unsigned long long)n);
-    }
-}
-
 // The same launch shape over the 4-wide collapse of the tree (bvh_wide.hpp): exact, half the dependent fetches.
 template <bool TWO_TRIS, class Source>
-__global__ __launch_bounds__(BLOCK, 8) __attribute__((amdgpu_num_sgpr(78))) void k_traverse_wide(WideView wide, const unsigned* __restrict__ count,
+__global__ __launch_bounds__(BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) void k_traverse_wide(WideView wide, const unsigned* __restrict__ count,
                                                         unsigned* __restrict__ work_counter, Source src, Stats* stats, int is_conn) {
     const unsigned n = *count;
     unsigned nb = 0, nt = 0;

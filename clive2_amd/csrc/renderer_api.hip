@@ -224,18 +224,6 @@ int launch_generate_both(cl2_renderer* r, hipStream_t st, const PathBufs* set) {
 inline size_t bvh_lds_bytes(const cl2_renderer* r) {
     return ((size_t)2 * r->bvh.n_lds_nodes + (r->bvh.lds_tris ? (size_t)3 * r->bvh.n_tris : 0)) * sizeof(float4);
 }
-// The cooperative walk keeps 13 KB of staging per workgroup in LDS; its node window is cut to what still lets eight
-// workgroups share a CU (debug_flags bits 16-19: window in units of 64 records, 0 = default 2 = 128 records).
-inline BvhView coop_view(const cl2_renderer* r) {
-    BvhView v = r->bvh;
-    const int units = (r->debug_flags >> 16) & 0xF;
-    v.n_lds_nodes = std::min(v.n_lds_nodes, 64 * (units ? units : 2));
-    return v;
-}
-inline size_t coop_lds_bytes(const cl2_renderer* r) {
-    const BvhView v = coop_view(r);
-    return ((size_t)2 * v.n_lds_nodes + (v.lds_tris ? (size_t)3 * v.n_tris : 0)) * sizeof(float4);
-}
 inline bool tree_in_lds(const cl2_renderer* r) { return r->bvh.lds_tris && r->bvh.n_nodes <= r->bvh.n_lds_nodes; }
 inline bool split_paths(const cl2_renderer* r) {
     if (r->traversal_mode == 1 || r->traversal_mode == 3) return false;
@@ -256,7 +244,7 @@ inline bool wide_walk(const cl2_renderer* r) {
     if (r->n_wide <= 0 || r->counting) return false;
     if (r->traversal_mode == 5) return true;
     const size_t bytes = (size_t)r->bvh.n_nodes * 32 + (size_t)r->bvh.n_tris * 48;
-    return r->traversal_mode == 0 && !tree_in_lds(r) && bytes <= ((size_t)16 << 20);
+    return (r->traversal_mode == 0 || r->traversal_mode == 4) && !tree_in_lds(r) && bytes <= ((size_t)16 << 20);
 }
 // Whole subpaths (light, then camera, all levels) in ONE persistent launch per sample (k_subpaths_persistent)
 // instead of a traversal + a bounce launch per level and kind: mode 4.  Measured at 1080p (ms per sample, serial order /
@@ -364,14 +352,8 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
                 r->launches_tp++;
             } else {
 #define CL2_PERSIST(CNT, TWO)                                                                                              \
-            do {                                                                                                           \
-                if (r->traversal_mode == 6)                                                                                \
-                    hipLaunchKernelGGL((k_traverse_coop<CNT, TWO, PathRaySource>), dim3(persistent_grid_paths(r)), dim3(BLOCK), coop_lds_bytes(r), \
-                                       st, coop_view(r), c_in, r->d_work + first, src, r->d_stats, 0);                      \
-                else                                                                                                       \
-                    hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, PathRaySource>), dim3(persistent_grid_paths(r)), dim3(BLOCK), bvh_lds_bytes(r), \
-                                       st, r->bvh, c_in, r->d_work + first, src, r->d_stats, 0);                           \
-            } while (0)
+            hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, PathRaySource>), dim3(persistent_grid_paths(r)), dim3(BLOCK), bvh_lds_bytes(r), \
+                               st, r->bvh, c_in, r->d_work + first, src, r->d_stats, 0)
             if (two_tris_per_step(r)) { if (r->counting) CL2_PERSIST(true, true); else CL2_PERSIST(false, true); }
             else { if (r->counting) CL2_PERSIST(true, false); else CL2_PERSIST(false, false); }
 #undef CL2_PERSIST
@@ -451,14 +433,8 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
                 TRY(launch_wide(r, st, 1, r->d_qcount + 7, r->d_work + 7, src, 1));
             } else {
 #define CL2_PERSIST(CNT, TWO)                                                                                             \
-            do {                                                                                                          \
-                if (r->traversal_mode == 6)                                                                               \
-                    hipLaunchKernelGGL((k_traverse_coop<CNT, TWO, ConnRaySource>), dim3(persistent_grid_conn(r)), dim3(BLOCK), coop_lds_bytes(r), \
-                                       st, coop_view(r), r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1);              \
-                else                                                                                                      \
-                    hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, ConnRaySource>), dim3(persistent_grid_conn(r)), dim3(BLOCK), bvh_lds_bytes(r), \
-                                       st, r->bvh, r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1);                   \
-            } while (0)
+            hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, ConnRaySource>), dim3(persistent_grid_conn(r)), dim3(BLOCK), bvh_lds_bytes(r), \
+                               st, r->bvh, r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1)
             if (two_tris_per_step(r)) { if (r->counting) CL2_PERSIST(true, true); else CL2_PERSIST(false, true); }
             else { if (r->counting) CL2_PERSIST(true, false); else CL2_PERSIST(false, false); }
 #undef CL2_PERSIST
@@ -1282,7 +1258,7 @@ int cl2_probe_bounce(cl2_renderer* r, int from_camera, const float* in, size_t n
 }
 int cl2_set_traversal_mode(cl2_renderer* r, int mode) {
     if (!r) return CL2_E_INVALID;
-    if (mode < 0 || mode > 6) return fail(r, CL2_E_INVALID, "traversal mode must be 0 (auto), 1 (fused), 2 (persistent, per level), 3 (fused subpaths, persistent connection rays), 4 (persistent whole subpaths) 5 (persistent, exact 4-wide walk) or 6 (persistent, cooperative triangle fetches)");
+    if (mode < 0 || mode > 5) return fail(r, CL2_E_INVALID, "traversal mode must be 0 (auto), 1 (fused), 2 (persistent, per level), 3 (fused subpaths, persistent connection rays), 4 (persistent whole subpaths) or 5 (persistent, exact 4-wide walk)");
     r->traversal_mode = mode;
     r->paths_share = 0;
     return CL2_OK;
@@ -1430,23 +1406,17 @@ int cl2_probe_traverse(cl2_renderer* r, const void* rays_v, size_t n_rays, int32
                   hipMemcpy(d_n, &n, sizeof n, hipMemcpyHostToDevice) == hipSuccess;
         if (!ok) rc = fail(r, CL2_E_HIP, "probe upload failed");
     }
-    if (rc == CL2_OK && r->traversal_mode >= 5 && r->n_wide > 0 && !r->counting) {
-        // the probe through the persistent organisations under test: the exact 4-wide walk with its left-over list (mode 5:
-        // rays with a non-finite 1/d go to the binary walk) or the cooperative walk (mode 6)
+    if (rc == CL2_OK && r->traversal_mode == 5 && r->n_wide > 0 && !r->counting) {
+        // the probe through the exact 4-wide walk with its left-over list (rays with a non-finite 1/d go to the binary walk)
         unsigned* d_left = nullptr;
         rc = dev_alloc(r, &d_left, n_rays);
         if (rc == CL2_OK && hipMemsetAsync(r->d_work, 0, sizeof(unsigned), r->stream) != hipSuccess) rc = fail(r, CL2_E_HIP, "probe memset failed");
         if (rc == CL2_OK) {
             PathRaySource src{nullptr, d_o, d_d, d_h, nullptr};
-            if (r->traversal_mode == 5) {
-                unsigned* keep = r->d_leftover[0];
-                r->d_leftover[0] = d_left;
-                rc = launch_wide(r, r->stream, 0, d_n, r->d_work, src, 0);
-                r->d_leftover[0] = keep;
-            } else {
-                hipLaunchKernelGGL((k_traverse_coop<false, true, PathRaySource>), dim3(persistent_grid()), dim3(BLOCK), coop_lds_bytes(r), r->stream,
-                                   coop_view(r), d_n, r->d_work, src, r->d_stats, 0);
-            }
+            unsigned* keep = r->d_leftover[0];
+            r->d_leftover[0] = d_left;
+            rc = launch_wide(r, r->stream, 0, d_n, r->d_work, src, 0);
+            r->d_leftover[0] = keep;
             if (rc == CL2_OK) rc = drain(r);
         }
         dev_free(r, d_left);

@@ -256,7 +256,7 @@ class Renderer:
     def set_traversal_mode(self, mode):
         """0 auto, 1 fused one-ray-per-lane kernels, 2 persistent traversal with ray replacement (one launch per
         level), 3 fused subpaths + persistent connection rays, 4 whole subpaths in one persistent launch, 5 exact 4-wide
-        walk for the connection rays, 6 cooperative triangle fetches."""
+        walk for the connection rays."""
         self._check(self._L.cl2_set_traversal_mode(self._h, int(mode)), "set_traversal_mode")
 
     def set_debug_flags(self, flags):

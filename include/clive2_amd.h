@@ -125,8 +125,7 @@ int cl2_set_levels_per_launch(cl2_renderer* r, int levels);
  * rays as in 2 (mid-size trees in serial order: no per-level launch tails), 4 = connection rays as in 2 and
  * both subpaths of a pixel -- light, then camera, all levels -- walked by one lane of ONE persistent launch
  * per sample, the bounces batched per wave (one launch tail instead of 24), 5 = as 2 with the connection rays walked
- * over an exact 4-wide collapse of the tree (half the dependent fetches, same decisions: csrc/bvh_wide.hpp), 6 = as 2
- * with triangles fetched cooperatively by the wave (measured slower; kept as an organisation under test), 0 (default)
+ * over an exact 4-wide collapse of the tree (half the dependent fetches, same decisions: csrc/bvh_wide.hpp), 0 (default)
  * = 1 for LDS-resident trees, otherwise 2 while the sample pipeline runs and 4 in serial order, with the 4-wide walk
  * for the connection rays when the tree is at most 16 MB.  Results are identical for every setting. */
 int cl2_set_traversal_mode(cl2_renderer* r, int mode);
@@ -210,8 +209,7 @@ int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
  * pipeline runs on a large scene (0 = tuned); bit 12 inverts the one/two-triangles-per-step choice of
  * the persistent walk; bit 3 sends the per-level subpath launches through the 4-wide walk too; 4-wide walk:
  * bits 16-19 stack entries per lane in LDS (0 = default 4), bits 20-23 LDS window in units of 32 wide nodes
- * (0 = default 2); cooperative walk (mode 6): bits 16-19 node window in units of 64 records; whole-subpath launch
- * (mode 4): bits 13-15 register budget as waves per SIMD (4, 5, 6;
+ * (0 = default 2); whole-subpath launch (mode 4): bits 13-15 register budget as waves per SIMD (4, 5, 6;
  * 7 = 8; 0 = default 5), bits 16-22 lanes gathered before a wave runs its bounce phase (0 = default 32),
  * bits 24-30 steps a finished lane waits at most (0 = default 48). */
 int cl2_set_debug_flags(cl2_renderer* r, int flags);

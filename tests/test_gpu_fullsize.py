@@ -303,7 +303,7 @@ def test_config5_real_size_vs_oracle(interior_real, oracle_mod):
     from clive2_amd.renderer import Renderer, make_seeds
     seeds = make_seeds(96 * 54)
     ref = None
-    for mode, flags in ((0, 1 << 12), (1, 0), (5, 8), (6, 0)):
+    for mode, flags in ((0, 1 << 12), (1, 0), (5, 8)):
         x = Renderer(interior_real, seeds=seeds)
         x.set_traversal_mode(mode); x.set_debug_flags(flags)
         x.make_light_rays(); x.make_camera_rays(); x.trace_light_rays(); x.trace_camera_rays()

@@ -50,11 +50,11 @@ def test_generated_rays_bit_exact(scene_name, request, oracle_mod):
 
 
 @pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
-@pytest.mark.parametrize("mode", [0, 5, 6])
+@pytest.mark.parametrize("mode", [0, 5])
 def test_closest_hit_bit_exact(scene_name, mode, request, oracle_mod):
     """traverse_bvh alone: camera rays, light rays and axis-parallel rays (inv_direction = +-inf) -- through the
     one-ray-per-lane kernel (mode 0), through the exact 4-wide walk (5: the axis-parallel rays must come back from its
-    left-over list, walked by the binary kernel, the others from the wide walk) and through the cooperative walk (6)."""
+    left-over list, walked by the binary kernel, the others from the wide walk)."""
     from clive2_amd import struct_types as st
     scene = request.getfixturevalue(scene_name)
     r, o = _pair(scene, oracle_mod)
@@ -161,7 +161,7 @@ def test_levels_per_launch_is_a_pure_performance_knob(levels, glass_scene, oracl
         r.set_levels_per_launch(7)
 
 
-@pytest.mark.parametrize("mode", [2, 4, 5, 6])
+@pytest.mark.parametrize("mode", [2, 4, 5])
 @pytest.mark.parametrize("flags", [0, 1 << 12, (4 << 13) | (1 << 16) | (1 << 24), (7 << 13) | (64 << 16) | (100 << 24) | (1 << 12)])
 @pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
 def test_persistent_traversal_mode_is_equivalent(scene_name, flags, mode, request, oracle_mod):
@@ -472,7 +472,7 @@ def test_movie_cli_writes_turntable_frames(tmp_path):
     assert not np.array_equal(frames[0], frames[1])        # the camera moved
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
 def test_sample_pipeline_is_a_pure_performance_knob(mode, glass_scene, oracle_mod):
     """run_samples as a pipeline over samples (later stages of sample i on their own streams beside
     the subpath stage of the next samples; 2 and 3 stages) == serial order == oracle: seeds, last

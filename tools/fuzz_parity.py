@@ -59,7 +59,7 @@ def main():
         B = scene.pixel_width * scene.pixel_height
         seeds = make_seeds(B, seed=k)
         r, o = Renderer(scene, seeds=seeds), orc.OracleRenderer(scene, seeds=seeds)
-        mode, levels, stages = int(rng.randint(0, 7)), int(rng.randint(0, 7)), int(rng.randint(-1, 3))
+        mode, levels, stages = int(rng.randint(0, 6)), int(rng.randint(0, 7)), int(rng.randint(-1, 3))
         r.set_traversal_mode(mode)
         if rng.rand() < 0.5:                # whole-subpath launch: random register budget and bounce batching, either step form
             r.set_debug_flags((int(rng.choice([0, 4, 5, 6, 7])) << 13) | (int(rng.randint(0, 65)) << 16) |
