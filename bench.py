@@ -267,10 +267,12 @@ def main():
         args.gpus = world
     if not os.path.exists("/dev/kfd"):
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    # CLIVE2_BENCH_SHARE_GPU=1 (rehearsal only, NOT used by the driver) would put every rank on device 0;
-    # RCCL refuses two ranks on one device, so a one-GPU box can only rehearse N = 1.
+    # RCCL refuses two ranks on one device, so a one-GPU box cannot rehearse N > 1; CLIVE2_BENCH_FORCE_COMM=1 (rehearsal
+    # only, NOT used by the driver) runs the N > 1 code path -- id exchange, communicator, barrier and clock through
+    # cl2_comm_allreduce_f64, the all-reduce inside the timed region -- on a one-rank communicator.
     W, H = args.width, args.height
-    res = run_workload(args, args.scene, W, H, args.steps, args.warmup, rank, local_rank, world, with_comm=world > 1)
+    with_comm = world > 1 or os.environ.get("CLIVE2_BENCH_FORCE_COMM") == "1"
+    res = run_workload(args, args.scene, W, H, args.steps, args.warmup, rank, local_rank, world, with_comm=with_comm)
 
     if rank == 0:
         out = {
@@ -285,7 +287,7 @@ def main():
                                    f"{args.steps} spp per GPU", "width": W, "height": H,
                        "rays_per_pixel_sample": round(res["rays_local"] / (args.steps * W * H), 3),
                        "parallelism": f"sample-split x{world}, one in-place RCCL all-reduce of the accumulators"
-                                      if world > 1 else "one GPU (no collective)"},
+                                      if with_comm else "one GPU (no collective)"},
             "roofline": res["roofline"],
             "stage_ms_per_step_serial": res["stages"],
         }
