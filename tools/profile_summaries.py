@@ -66,8 +66,11 @@ def main():
         # average active lanes per VALU wave-instruction: thread-cycles / (4 cycles per quad-cycle-counted instruction)
         if row.get("SQ_THREAD_CYCLES_VALU") and row.get("SQ_INSTS_VALU"):
             row["thread_cycles_per_valu_inst"] = round(row["SQ_THREAD_CYCLES_VALU"] / row["SQ_INSTS_VALU"], 2)
-    conn = [k for k in kernels if (k.startswith("k_traverse_conn<false") or
-                                   (k.startswith("k_traverse_persistent<false") and "ConnRaySource" in k))]
+    # the connection-ray traversal launch: the 4-wide walk where the scene uses it (its left-over launch of the binary
+    # kernel carries a handful of rays), else the binary persistent walk, else the LDS kernel of the small scenes
+    conn = ([k for k in kernels if k.startswith("k_traverse_wide<") and "ConnRaySource" in k] or
+            [k for k in kernels if k.startswith("k_traverse_persistent<false") and "ConnRaySource" in k] or
+            [k for k in kernels if k.startswith("k_traverse_conn<false")])
     out = {"note": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*, TCC_* each in its own run, --kernel-trace only) of "
                    f"`python3 bench.py --scene {scene} --no-cpu-baseline --no-mesh --steps 4 --warmup 1`; values are averages per launch; "
                    "FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count, "
