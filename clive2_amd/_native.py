@@ -108,6 +108,9 @@ def lib(variant=None):
         if not os.path.exists(path):
             raise RendererError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the render path.")
+        # The ROCm runtime reads this when it initialises (first HIP call): on hosts whose driver only supports dmabuf IPC,
+        # RCCL between processes fails with `hipIpcGetMemHandle: invalid argument` without it.  An explicit setting wins.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         L = C.CDLL(path)
         L.cl2_last_error.restype = C.c_char_p
         L.cl2_last_error.argtypes = [C.c_void_p]
