@@ -252,9 +252,11 @@ inline bool wide_walk(const cl2_renderer* r) {
 // One launch has one tail instead of 24, which is what the serial order pays for; the sample pipeline already fills
 // those tails with the other stage's work, and there the whole-subpath launch loses to its own costs (5 instead of 8
 // waves per SIMD for the bounce code's registers; vertex stores scattered over unrelated pixels: 7.7 GB written per
-// launch against 1.7 GB of vertices).  So the automatic choice takes it in the serial order only.
+// launch against 1.7 GB of vertices).  And a level launch of a 4K frame (8.3 M rays, 16 per lane) has little tail to
+// lose: there the per-level form wins in serial order too (interior 4K: 53.7 vs 61.6 ms of subpath time, blob 24.0 vs
+// 28.1).  So the automatic choice takes it in the serial order and up to 2^22 pixels only.
 inline bool whole_subpaths(const cl2_renderer* r) {
-    return r->traversal_mode == 4 || (r->traversal_mode == 0 && !tree_in_lds(r) && !r->pipe_active);
+    return r->traversal_mode == 4 || (r->traversal_mode == 0 && !tree_in_lds(r) && !r->pipe_active && r->B <= (1 << 22));
 }
 // Two triangles per step of the persistent walk while the tree is cache-resident (the step is then
 // issue-bound and fewer, fatter steps win: glass +5 %, blob +4 %); one when it streams from memory
