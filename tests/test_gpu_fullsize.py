@@ -99,6 +99,10 @@ def test_config3_glass_sphere_vs_oracle(oracle_mod):
     assert r.counters()["rays"] == o.rays_traced
 
 
+def test_config3_1080p_wide_walk_equals_binary():
+    _wide_equals_binary_at_full_frame(_glass(4, 1920, 1080))
+
+
 def test_config3_1080p_properties():
     from clive2_amd.renderer import Renderer
     scene = _glass(4, 1920, 1080)
@@ -281,11 +285,31 @@ def test_config4_real_size_vs_oracle(blob_real, oracle_mod):
     assert 12 < c["box_tests"] / c["counted_rays"] < 22       # N_node 16.3 at 1080p
 
 
+def _wide_equals_binary_at_full_frame(scene):
+    """One full-frame sample with the connection rays on the exact 4-wide walk and one on the binary walk: the filter
+    aggregators (no atomics on that path) must be the same bytes -- tens of millions of connection rays per comparison."""
+    from clive2_amd.renderer import Renderer, make_seeds
+    seeds = make_seeds(scene.pixel_width * scene.pixel_height)
+    out = []
+    for mode in (0, 2):
+        x = Renderer(scene, seeds=seeds)
+        x.set_traversal_mode(mode)
+        assert x.organisation()["wide_connections"] == (1 if mode == 0 else 0)
+        x.make_light_rays(); x.make_camera_rays(); x.trace_light_rays(); x.trace_camera_rays(); x.join_paths()
+        agg = x.export_aggregators()
+        out.append((agg["total_contribution"].tobytes(), agg["contrib_weight_sum"].tobytes(), x.counters()["conn_rays"]))
+        x.close()
+    assert out[0][2] == out[1][2] and out[0][2] > 10 * scene.pixel_width * scene.pixel_height
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+
+
 def test_config4_real_size_1080p_properties(blob_real):
     """(b) the HIP path at the config's frame, 1920x1080, 2 samples."""
     r, c = _full_frame_properties(blob_real.with_resolution(1920, 1080), 2)
     assert r.organisation()["persistent_connections"] == 1
     assert 14 < c["box_tests"] / c["counted_rays"] < 19 and 10 < c["tri_tests"] / c["counted_rays"] < 16
+    r.close()
+    _wide_equals_binary_at_full_frame(blob_real.with_resolution(1920, 1080))
 
 
 def test_config5_real_size_vs_oracle(interior_real, oracle_mod):
