@@ -132,3 +132,51 @@ def test_make_seeds_contract():
     assert not np.array_equal(a, make_seeds(100, rank=1))
     ref = np.random.RandomState(20240928).randint(0, 2 ** 32, size=(100, 2), dtype=np.uint32)
     assert np.array_equal(a[ref != 0], ref[ref != 0])
+
+
+def _build_c_client(tmp_path):
+    import subprocess
+    from clive2_amd import _native
+    _native.build()
+    exe = str(tmp_path / "c_abi_client")
+    lib_dir = os.path.dirname(_native.LIB_PATH)
+    cmd = ["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_client.c"),
+           "-o", exe, "-L", lib_dir, "-lclive2_amd", f"-Wl,-rpath,{lib_dir}"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """include/clive2_amd.h compiles as C (gcc, -Wall -Werror) and a plain-C program links against the library: the
+    boundary needs no Python and no C++ on the caller's side (examples/c_abi_client.c)."""
+    exe = _build_c_client(tmp_path)
+    assert os.path.exists(exe)
+
+
+@pytest.mark.gpu
+def test_c_client_renders_the_same_accumulators_as_the_python_binding(tmp_path):
+    """The plain-C client (examples/c_abi_client.c) fed with the raw scene arrays renders the same samples as the ctypes
+    `Renderer`: unidirectional buffer and counts bit for bit, image within the splat-order tolerance."""
+    import subprocess
+    import clive2_amd as c2
+    from clive2_amd.renderer import Renderer, make_seeds
+    exe = _build_c_client(tmp_path)
+    W, H, n = 96, 64, 5
+    scene = c2.create_scene_from_preset("empty", W, H)
+    seeds = make_seeds(W * H)
+    for name, arr in (("boxes", scene.boxes), ("triangles", scene.triangles), ("materials", scene.materials),
+                      ("camera", scene.camera), ("light_triangles", scene.light_triangles),
+                      ("light_areas", np.asarray(scene.light_surface_areas, np.float32)),
+                      ("light_indices", np.asarray(scene.light_triangle_indices, np.int32)), ("seeds", seeds)):
+        np.ascontiguousarray(arr).tofile(tmp_path / f"{name}.bin")
+    res = subprocess.run([exe, str(tmp_path), str(W), str(H), str(n)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, (res.stdout, res.stderr)
+    r = Renderer(scene, seeds=seeds)
+    r.run_samples(n)
+    img, wts, cnt, uni = r.read_accumulators()
+    assert f"{r.counters()['rays']} rays" in res.stdout
+    assert np.fromfile(tmp_path / "unidirectional.bin", np.float32).tobytes() == uni.tobytes()
+    assert np.fromfile(tmp_path / "counts.bin", np.int32).tobytes() == cnt.tobytes()
+    np.testing.assert_allclose(np.fromfile(tmp_path / "summed_image.bin", np.float32).reshape(H, W, 3), img, rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(np.fromfile(tmp_path / "summed_weights.bin", np.float32).reshape(H, W, 1), wts, rtol=2e-5, atol=1e-9)
