@@ -238,8 +238,7 @@ inline bool split_conn(const cl2_renderer* r) {
 // glass scene, 6.98 -> 6.02 ms on the blob (sample pipeline: 13.7 -> 12.5 ms, 16.6 -> 15.4 ms).  A 155 MB tree walks
 // slower this way (15.7 -> 18.6 ms: a wide node moves a whole 128-byte line per visit, used or not, and that walk is
 // bound by the bytes that miss L2), so it keeps the binary walk.  Never while counting: the node-test tallies are
-// defined by the binary walk.  The per-level subpath launches (tail-bound, 2 M rays each) gain nothing from it
-// (debug_flags bit 3 sends them through it anyway, for tests).
+// defined by the binary walk.  The per-level subpath launches use it while the sample pipeline runs (launch_trace).
 inline bool wide_walk(const cl2_renderer* r) {
     if (r->n_wide <= 0 || r->counting) return false;
     if (r->traversal_mode == 5) return true;
@@ -349,7 +348,11 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
         if (split) {
             Timed t(r, ST_TRAVERSE_PATHS, st);
             PathRaySource src{q_in, pb.P0 + (size_t)first * B, pb.P1 + (size_t)first * B, r->d_hit, nullptr};
-            if (wide_walk(r) && ((r->debug_flags >> 3) & 1)) {      // experiment switch: the per-level subpath launches too
+            // the per-level subpath launches take the 4-wide walk while the sample pipeline runs: alone they are tail-bound and
+            // gain nothing (glass 7.43 -> 7.56 ms), but beside the connection stage what counts is the work they put on
+            // the machine (-20 % VALU): 12.43 -> 12.19 ms per sample on the glass scene, 15.38 -> 15.0 on the blob.
+            // debug_flags bit 3 forces it in the serial order too (tests)
+            if (wide_walk(r) && (r->pipe_active || ((r->debug_flags >> 3) & 1))) {
                 TRY(launch_wide(r, st, 0, c_in, r->d_work + first, src, 0));
                 r->launches_tp++;
             } else {
