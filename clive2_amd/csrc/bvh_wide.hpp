@@ -30,6 +30,17 @@ namespace cl2 {
 
 constexpr int WIDE_EMPTY = (int)0x80000000;
 constexpr int WIDE_STACK_LDS = 8;
+// Triangle pairs a lane in a leaf tests per pass.  The pass -- its refill check, its node block for the other lanes, its
+// bookkeeping, its dependent fetch -- is the unit of cost of the persistent walks, so a leaf of three or four
+// triangles should not take two of them: a second pair in the same pass (fetched after the first is tested) took the
+// connection launch from 4.78 to 3.78 ms on the glass scene and from 5.94 to 4.99 ms on the blob (three pairs: 4.15 /
+// 5.45, four: 3.69 / 5.14).
+#ifndef WIDE_TRI_REPS
+#define WIDE_TRI_REPS 2
+#endif
+// (Two node visits per pass, by the same reasoning, do NOT pay: 3.80 -> 4.12 ms; nor does a second triangle round in the
+// binary walks, whose pass already tests the first triangles of a leaf together with the node visit that enters it:
+// whole-subpath launch 5.87 -> 6.30 ms on the glass scene, connection launch of the 1M-triangle scene 15.8 -> 16.3 ms.)
 constexpr int WIDE_STACK_OVERFLOW = 136;      // 2 x the reference's 64-entry stack bound + slack: cannot be exceeded (Q18 check at upload)
 
 struct WideView {
@@ -151,6 +162,8 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, unsi
                 }
                 pop_next();
             }
+#pragma unroll
+            for (int rep = 0; rep < (TWO_TRIS ? WIDE_TRI_REPS : 1); rep++)
             if (tri_i < tri_end) {
                 const int i0 = tri_i;
                 const bool two = TWO_TRIS && i0 + 1 < tri_end;
