@@ -537,14 +537,32 @@ __global__ __launch_bounds__(BLOCK, 6) void k_trace_subpath(
 // sample with one tail.  Same arithmetic on the same operands in the same order per path: identical results.
 enum { LANE_IDLE = 0, LANE_TRAV = 1, LANE_PEND = 2 };
 
-template <bool COUNT, bool TWO_TRIS, int WAVES_PER_SIMD>
+// WIDE: the lanes walk the exact 4-wide collapse of the tree (bvh_wide.hpp: wide node block, per-lane stack in LDS, two
+// triangle pairs per pass) -- except the rays with a non-finite 1/d, which keep the binary walk (records read through
+// the caches), since a whole-subpath lane cannot hand its ray to a left-over launch.
+template <bool COUNT, bool TWO_TRIS, int WAVES_PER_SIMD, bool WIDE>
 __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
-        BvhView bvh, int B, unsigned* __restrict__ work_counter, PathBufs lp, PathBufs cp, uint2* __restrict__ seeds,
+        BvhView bvh, WideView wide, int B, unsigned* __restrict__ work_counter, PathBufs lp, PathBufs cp, uint2* __restrict__ seeds,
         const float4* __restrict__ tri_shade_g, const MaterialDev* __restrict__ mats_g, int n_mats, Stats* stats,
         int bounce_lanes, int bounce_wait, int kinds /* 1 light subpaths only, 2 camera only, 3 both (light first) */) {
     BvhLds s{nullptr, nullptr};
-    stage_bvh(s, bvh);                                     // ends with the barrier
-    const BvhView& b = bvh;
+    BvhView b = bvh;
+    // WIDE: LDS holds the top of the wide tree and the per-lane stacks instead of the binary window
+    extern __shared__ float4 cl2_tree_lds[];
+    const int tid = threadIdx.x;
+    const int S = wide.stack_lds;
+    float4* s_wnodes = cl2_tree_lds;
+    int* s_ref = reinterpret_cast<int*>(cl2_tree_lds + 8 * wide.n_lds_nodes);
+    float* s_tmin = reinterpret_cast<float*>(s_ref) + S * BLOCK;
+    int2* ovf = nullptr;
+    if (WIDE) {
+        for (int i = tid; i < 8 * wide.n_lds_nodes; i += BLOCK) s_wnodes[i] = wide.nodes[i];
+        __syncthreads();
+        b.n_lds_nodes = 0; b.lds_tris = 0;                 // the binary records (rays with a non-finite 1/d) come through the caches
+        ovf = wide.overflow + ((size_t)blockIdx.x * BLOCK + tid) * WIDE_STACK_OVERFLOW;
+    } else {
+        stage_bvh(s, bvh);                                 // ends with the barrier
+    }
     // shading records and the (tiny) material table are read through the caches: this launch is for trees
     // that do not fit LDS, whose shading triangles do not either
     const ShadeSrc src{nullptr, false, false, tri_shade_g, mats_g};
@@ -566,6 +584,8 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
     Hit best{-1, __builtin_inff(), 0.0f, 0.0f};
     const int n_nodes = b.n_nodes;
     int node = n_nodes, tri_i = 0, tri_end = 0;
+    int cur = -1, sp = 0;                                  // WIDE: wide node to visit next (-1 none), stack depth
+    bool wlane = false;                                    // WIDE: this ray walks the wide tree
     unsigned n_box = 0, n_tri = 0, n_rays = 0;
 
     // (re)start the walk of the current subpath at vertex `level` (its outgoing ray was stored with the vertex)
@@ -575,8 +595,36 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
         fast = finite3(inv);
         best = Hit{-1, __builtin_inff(), 0.0f, 0.0f};
         node = 0; tri_i = 0; tri_end = 0;
+        cur = -1; sp = 0; wlane = false;
+        if (WIDE && fast) {
+            wlane = true;
+            node = n_nodes;
+            // the root box, trace.metal:150-156 with best_t = inf
+            const float t0x = (wide.root_lo.x - o.x) * inv.x, t0y = (wide.root_lo.y - o.y) * inv.y, t0z = (wide.root_lo.z - o.z) * inv.z;
+            const float t1x = (wide.root_hi.x - o.x) * inv.x, t1y = (wide.root_hi.y - o.y) * inv.y, t1z = (wide.root_hi.z - o.z) * inv.z;
+            const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                                               __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
+            const float tmax = __builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
+            if (tmin <= tmax) cur = 0;
+        }
         state = LANE_TRAV;
         n_rays++;
+    };
+    auto push = [&](int ref, float tmin) {
+        if (sp < S) { s_ref[sp * BLOCK + tid] = ref; s_tmin[sp * BLOCK + tid] = tmin; }
+        else ovf[sp - S] = make_int2(ref, __float_as_int(tmin));
+        sp++;
+    };
+    auto pop_next = [&]() {
+        while (sp > 0 && cur < 0 && tri_i >= tri_end) {
+            sp--;
+            int ref; float tmin;
+            if (sp < S) { ref = s_ref[sp * BLOCK + tid]; tmin = s_tmin[sp * BLOCK + tid]; }
+            else { const int2 e = ovf[sp - S]; ref = e.x; tmin = __int_as_float(e.y); }
+            if (!(tmin < best.t)) continue;
+            if (ref >= 0) cur = ref;
+            else { const int info = ~ref; tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
+        }
     };
 
     while (true) {
@@ -653,10 +701,32 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
             continue;                                      // refill the lanes that went idle before the next step
         }
 
-        // ---- one traversal step per walking lane (the step of traverse_persistent) ----
-        const bool all_fast = __all(state != LANE_TRAV || fast);
+        // ---- one traversal step per walking lane (the step of traverse_persistent, or of traverse_wide_persistent) ----
+        const bool all_fast = !WIDE && __all(state != LANE_TRAV || fast);    // WIDE: the binary block only sees non-finite rays
         if (state == LANE_TRAV) {
-            if (tri_i >= tri_end && node < n_nodes) {
+            if (WIDE && wlane) {
+                pop_next();
+                if (cur >= 0) {
+                    const float4* nd = cur < wide.n_lds_nodes ? s_wnodes + 8 * cur : wide.nodes + (size_t)8 * cur;
+                    const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
+                    const float4 rf = nd[6];
+                    cur = -1;
+                    const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
+                    const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
+                    const int ref[4] = {__float_as_int(rf.x), __float_as_int(rf.y), __float_as_int(rf.z), __float_as_int(rf.w)};
+#pragma unroll
+                    for (int k = 3; k >= 0; k--) {
+                        if (ref[k] == WIDE_EMPTY) continue;
+                        const float t0x = (lox[k] - o.x) * inv.x, t0y = (loy[k] - o.y) * inv.y, t0z = (loz[k] - o.z) * inv.z;
+                        const float t1x = (hix[k] - o.x) * inv.x, t1y = (hiy[k] - o.y) * inv.y, t1z = (hiz[k] - o.z) * inv.z;
+                        const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                                                           __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
+                        const float tmax = __builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
+                        if (tmin <= tmax && tmin < best.t) push(ref[k], tmin);
+                    }
+                    pop_next();
+                }
+            } else if (tri_i >= tri_end && node < n_nodes) {
                 float4 lo, hi;
                 if (node < b.n_lds_nodes) { lo = s.nodes[2 * node]; hi = s.nodes[2 * node + 1]; }
                 else { lo = b.nodes[2 * node]; hi = b.nodes[2 * node + 1]; }
@@ -680,7 +750,9 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
                     else { tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
                 }
             }
-            if (tri_i < tri_end) {
+#pragma unroll
+            for (int rep = 0; rep < (WIDE ? WIDE_TRI_REPS : 1); rep++)
+            if (tri_i < tri_end && (rep == 0 || wlane)) {
                 const int i0 = tri_i;
                 const bool two = TWO_TRIS && i0 + 1 < tri_end;
                 const int i1 = two ? i0 + 1 : i0;
@@ -697,7 +769,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
                 tri_test(o, d, a0, a1, a2, i0, best);
                 if (TWO_TRIS && two) tri_test(o, d, c0, c1, c2, i1, best);
             }
-            if (tri_i >= tri_end && node >= n_nodes) state = LANE_PEND;
+            if (tri_i >= tri_end && ((WIDE && wlane) ? (cur < 0 && sp == 0) : node >= n_nodes)) state = LANE_PEND;
         }
     }
 

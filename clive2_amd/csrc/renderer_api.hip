@@ -394,8 +394,19 @@ int launch_subpaths(cl2_renderer* r, hipStream_t st, const PathBufs* set, int ki
     // lanes gathered / steps waited before a wave runs its bounce phase (debug_flags bits 16-22 / 24-30 override)
     const int lanes = ((r->debug_flags >> 16) & 0x7F) ? ((r->debug_flags >> 16) & 0x7F) : 32;
     const int wait = ((r->debug_flags >> 24) & 0x7F) ? ((r->debug_flags >> 24) & 0x7F) : 48;
-#define CL2_WHOLE(CNT, TWO, WPS)                                                                                         \
-    hipLaunchKernelGGL((k_subpaths_persistent<CNT, TWO, WPS>), dim3(grid), dim3(BLOCK), bvh_lds_bytes(r), st, r->bvh, \
+    // the exact 4-wide walk inside the launch where the scene has it (same rule as the connection rays)
+    const bool widew = wide_walk(r) && two_tris_per_step(r);
+    WideView w = r->wide;
+    const int sflag = (r->debug_flags >> 16) & 0xF, wflag = (r->debug_flags >> 20) & 0xF;
+    w.stack_lds = 4; w.n_lds_nodes = 0;
+    if (widew) {
+        (void)sflag; (void)wflag;
+        w.n_lds_nodes = std::min(r->n_wide, 64);
+        w.overflow = r->d_wide_ovf;                            // stage 0 region: the subpath stage
+    }
+    const size_t lds = widew ? (size_t)w.stack_lds * BLOCK * 8 + (size_t)w.n_lds_nodes * 128 : bvh_lds_bytes(r);
+#define CL2_WHOLE(CNT, TWO, WPS, WIDE)                                                                                    \
+    hipLaunchKernelGGL((k_subpaths_persistent<CNT, TWO, WPS, WIDE>), dim3(grid), dim3(BLOCK), lds, st, r->bvh, w,          \
                        r->B, r->d_work, set[CL2_LIGHT], set[CL2_CAMERA], r->d_seeds, r->d_tri_shade, r->d_mats, r->n_mats, \
                        r->d_stats, lanes, wait, kinds)
     // experiment switch (debug_flags bits 13-15): register budget of the launch as waves per SIMD (4, 5, 6; 7 = 8 waves), 0 = default
@@ -405,8 +416,9 @@ int launch_subpaths(cl2_renderer* r, hipStream_t st, const PathBufs* set, int ki
     const int grid = std::max(1, persistent_grid_paths(r) * std::min(wps, 8) / 8);
 #define CL2_WHOLE_W(WPS)                                                                                                 \
     do {                                                                                                                 \
-        if (two_tris_per_step(r)) { if (r->counting) CL2_WHOLE(true, true, WPS); else CL2_WHOLE(false, true, WPS); }      \
-        else { if (r->counting) CL2_WHOLE(true, false, WPS); else CL2_WHOLE(false, false, WPS); }                         \
+        if (widew) CL2_WHOLE(false, true, WPS, true);                                                                     \
+        else if (two_tris_per_step(r)) { if (r->counting) CL2_WHOLE(true, true, WPS, false); else CL2_WHOLE(false, true, WPS, false); } \
+        else { if (r->counting) CL2_WHOLE(true, false, WPS, false); else CL2_WHOLE(false, false, WPS, false); }            \
     } while (0)
     if (wps <= 4) CL2_WHOLE_W(4); else if (wps == 5) CL2_WHOLE_W(5); else if (wps == 6) CL2_WHOLE_W(6); else CL2_WHOLE_W(8);
 #undef CL2_WHOLE_W
