@@ -16,8 +16,8 @@
 // (one 128-byte line per two levels) and of loop passes.
 //
 // Rays with a non-finite 1/d (a direction component is exactly 0: 0 * inf = NaN breaks the monotonicity argument)
-// are not walked here: their queue positions go to a left-over list that the binary walk (traverse_persistent)
-// processes afterwards.
+// do not walk the wide tree: their lanes run the binary stackless walk of traverse_persistent inside the same loop
+// (records read through the caches, MSL min/max), so a launch needs no second pass for them.
 //
 // Wide node = 8 x float4: {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]} {hi.z[4]} {ref[4] as int} {pad}
 //   ref >= 0: wide node index; ref < 0 and != WIDE_EMPTY: leaf, ~ref = first_triangle << 4 | count - 1; WIDE_EMPTY: no slot.
@@ -48,14 +48,12 @@ struct WideView {
     const float4* tris;        // 3 float4 per triangle (the binary walk's array)
     float4 root_lo, root_hi;   // the root box: tested once per ray, as the reference does
     int2* overflow;            // [lanes of the launch][WIDE_STACK_OVERFLOW]
-    unsigned* leftover;        // queue positions of rays with a non-finite 1/d ...
-    unsigned* leftover_count;  // ... and how many
     int stack_lds;             // stack entries kept in LDS per lane (<= WIDE_STACK_LDS)
     int n_lds_nodes;           // wide nodes [0, n_lds_nodes) (breadth-first numbering: the top of the tree) staged in LDS
 };
 
 template <bool COUNT, bool TWO_TRIS, class Source>
-__device__ __forceinline__ void traverse_wide_persistent(const WideView& w, unsigned n, unsigned* work_counter, const Source& src,
+__device__ __forceinline__ void traverse_wide_persistent(const WideView& w, const BvhView& b, unsigned n, unsigned* work_counter, const Source& src,
                                                          unsigned& n_box, unsigned& n_tri) {
     extern __shared__ float4 cl2_tree_lds[];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -77,6 +75,9 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, unsi
     V3 o = v3(0, 0, 0), d = o, inv = o;
     Hit best{-1, __builtin_inff(), 0.0f, 0.0f};
     int cur = -1, tri_i = 0, tri_end = 0, sp = 0;
+    int node = 0x7fffffff;                     // binary walk of a ray with a non-finite 1/d (wlane == false)
+    bool wlane = true;
+    const int n_nodes = b.n_nodes;
     unsigned key = 0;
 
     auto push = [&](int ref, float tmin) {
@@ -116,11 +117,12 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, unsi
                 key = w_next + rank;
                 src.load(key, o, d);
                 inv = rcp3(d);
-                if (!finite3(inv)) {
-                    w.leftover[atomicAdd(w.leftover_count, 1u)] = key;      // walked by the binary kernel afterwards
-                } else {
-                    best = Hit{-1, __builtin_inff(), 0.0f, 0.0f};
-                    cur = -1; tri_i = 0; tri_end = 0; sp = 0;
+                best = Hit{-1, __builtin_inff(), 0.0f, 0.0f};
+                cur = -1; tri_i = 0; tri_end = 0; sp = 0;
+                wlane = finite3(inv);
+                node = wlane ? n_nodes : 0;
+                active = true;
+                if (wlane) {
                     // the root box, trace.metal:150-156 with best_t = inf
                     const float t0x = (w.root_lo.x - o.x) * inv.x, t0y = (w.root_lo.y - o.y) * inv.y, t0z = (w.root_lo.z - o.z) * inv.z;
                     const float t1x = (w.root_hi.x - o.x) * inv.x, t1y = (w.root_hi.y - o.y) * inv.y, t1z = (w.root_hi.z - o.z) * inv.z;
@@ -129,7 +131,6 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, unsi
                     const float tmax = __builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
                     if (COUNT) n_box++;
                     if (tmin <= tmax && tmin < best.t) cur = 0;
-                    active = true;
                 }
             }
             const unsigned taken = __popcll(idle) < avail ? __popcll(idle) : avail;
@@ -139,6 +140,22 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, unsi
         if (!__any(active)) break;
 
         if (active) {
+            if (!wlane) {
+                if (tri_i >= tri_end && node < n_nodes) {
+                    const float4 lo = b.nodes[2 * node], hi = b.nodes[2 * node + 1];
+                    const int next = __float_as_int(lo.w);
+                    const float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
+                    const float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
+                    const float tmin = max_msl(max_msl(min_msl(t0x, t1x), min_msl(t0y, t1y)), max_msl(min_msl(t0z, t1z), 0.0f));
+                    const float tmax = min_msl(min_msl(max_msl(t0x, t1x), max_msl(t0y, t1y)), min_msl(max_msl(t0z, t1z), __builtin_inff()));
+                    node = next;
+                    if (tmin <= tmax && tmin < best.t) {
+                        const int info = __float_as_int(hi.w);
+                        if (info < 0) node = ~info;
+                        else { tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
+                    }
+                }
+            } else {
             pop_next();                                                     // lanes that finished a leaf in the previous pass
             if (cur >= 0) {
                 // one wide node: the slab tests of up to four boxes, in the reference's visit order (slot 0 first)
@@ -162,9 +179,10 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, unsi
                 }
                 pop_next();
             }
+            }
 #pragma unroll
             for (int rep = 0; rep < (TWO_TRIS ? WIDE_TRI_REPS : 1); rep++)
-            if (tri_i < tri_end) {
+            if (tri_i < tri_end && (rep == 0 || wlane)) {
                 const int i0 = tri_i;
                 const bool two = TWO_TRIS && i0 + 1 < tri_end;
                 const int i1 = two ? i0 + 1 : i0;
@@ -176,7 +194,7 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, unsi
                 tri_test(o, d, a0, a1, a2, i0, best);
                 if (TWO_TRIS && two) tri_test(o, d, c0, c1, c2, i1, best);
             }
-            if (tri_i >= tri_end && cur < 0 && sp == 0) {
+            if (tri_i >= tri_end && (wlane ? (cur < 0 && sp == 0) : node >= n_nodes)) {
                 src.store(key, best);
                 active = false;
             }

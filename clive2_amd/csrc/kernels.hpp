@@ -215,8 +215,7 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_paths(
 // ---------------------------------------------------------------- persistent traversal kernels (large scenes)
 struct PathRaySource {          // subpath rays: queue entry -> pixel -> (P0.xyz, P1.xyz) of one level
     const int* queue; const float4* P0v; const float4* P1v; float4* hit;
-    const unsigned* remap;      // non-null: ray j of this launch is queue position remap[j] (left-over list of the wide walk)
-    __device__ __forceinline__ int pid(unsigned j) const { if (remap) j = remap[j]; return queue ? queue[j] : (int)j; }
+    __device__ __forceinline__ int pid(unsigned j) const { return queue ? queue[j] : (int)j; }
     __device__ __forceinline__ void load(unsigned j, V3& o, V3& d) const { const int p = pid(j); o = v3(P0v[p]); d = v3(P1v[p]); }
     __device__ __forceinline__ void store(unsigned j, const Hit& h) const {
         hit[pid(j)] = make_float4(__int_as_float(h.tri), h.t, h.u, h.v);
@@ -239,9 +238,8 @@ __device__ __forceinline__ float2 chit_load(const float2* chit, int B, int t, in
 
 struct ConnRaySource {          // connection rays: tag {slot, pixel} -> light vertex s-1 toward focal point / camera vertex t-1
     const int* ctag; const float4* LP0; const float4* CP0; float2* chit; V3 focal; int B;
-    const unsigned* remap;      // as in PathRaySource
     __device__ __forceinline__ void load(unsigned j, V3& o, V3& d) const {
-        const int tag = ctag[remap ? remap[j] : j];
+        const int tag = ctag[j];
         const int pid = tag & ((1 << TAG_PID_BITS) - 1), slot = (unsigned)tag >> TAG_PID_BITS;
         const int t = slot / 6 + 1, s = slot % 6 + 1;
         o = v3(LP0[(size_t)(s - 1) * B + pid]);
@@ -250,7 +248,7 @@ struct ConnRaySource {          // connection rays: tag {slot, pixel} -> light v
         d = normalize(target - o);
     }
     __device__ __forceinline__ void store(unsigned j, const Hit& h) const {
-        const int tag = ctag[remap ? remap[j] : j];
+        const int tag = ctag[j];
         const int pid = tag & ((1 << TAG_PID_BITS) - 1), slot = (unsigned)tag >> TAG_PID_BITS;
         chit_store(chit, B, slot, pid, h.tri, h.t);
     }
@@ -275,21 +273,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(78))) void k_
             atomicAdd(&stats->tri_tests, (unsigned long long)nt);
         }
     }
-    if (is_conn >= 0 && blockIdx.x == 0 && threadIdx.x == 0) {      // is_conn < 0: left-over launch of a wide walk, tallied there
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&stats->rays, (unsigned long long)n);
-        if (is_conn > 0) atomicAdd(&stats->conn_rays, (unsigned long long)n);
+        if (is_conn) atomicAdd(&stats->conn_rays, (unsigned long long)n);
         if (COUNT) atomicAdd(&stats->counted_rays, (unsigned long long)n);
     }
 }
 
 // The same launch shape over the 4-wide collapse of the tree (bvh_wide.hpp): exact, half the dependent fetches.
 template <bool TWO_TRIS, class Source>
-__global__ __launch_bounds__(BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) void k_traverse_wide(WideView wide, const unsigned* __restrict__ count,
+__global__ __launch_bounds__(BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) void k_traverse_wide(WideView wide, BvhView bvh, const unsigned* __restrict__ count,
                                                         unsigned* __restrict__ work_counter, Source src, Stats* stats, int is_conn) {
     const unsigned n = *count;
     unsigned nb = 0, nt = 0;
-    traverse_wide_persistent<false, TWO_TRIS>(wide, n, work_counter, src, nb, nt);
-    // all n rays of the launch are tallied here, the left-over ones included (their binary launch runs with is_conn < 0)
+    traverse_wide_persistent<false, TWO_TRIS>(wide, bvh, n, work_counter, src, nb, nt);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&stats->rays, (unsigned long long)n);
         if (is_conn) atomicAdd(&stats->conn_rays, (unsigned long long)n);
@@ -539,7 +536,7 @@ enum { LANE_IDLE = 0, LANE_TRAV = 1, LANE_PEND = 2 };
 
 // WIDE: the lanes walk the exact 4-wide collapse of the tree (bvh_wide.hpp: wide node block, per-lane stack in LDS, two
 // triangle pairs per pass) -- except the rays with a non-finite 1/d, which keep the binary walk (records read through
-// the caches), since a whole-subpath lane cannot hand its ray to a left-over launch.
+// the caches), as in traverse_wide_persistent.
 template <bool COUNT, bool TWO_TRIS, int WAVES_PER_SIMD, bool WIDE>
 __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
         BvhView bvh, WideView wide, int B, unsigned* __restrict__ work_counter, PathBufs lp, PathBufs cp, uint2* __restrict__ seeds,

@@ -73,8 +73,6 @@ struct cl2_renderer {
     int n_wide = 0;
     WideView wide{};
     int2* d_wide_ovf = nullptr;          // per-lane stack overflow of the wide launches (one region per stage: [2])
-    unsigned* d_leftover[2] = {nullptr, nullptr};   // [0] subpath stage, [1] connection stage: queue positions + count
-    unsigned* d_leftover_count = nullptr;            // [2]
     CameraRec cam{};
 
     // state
@@ -298,33 +296,24 @@ inline int persistent_grid_conn(const cl2_renderer* r) {
     return (r->pipe_active && e < 8) ? 256 * (8 - e) : persistent_grid();
 }
 
-// One persistent launch of the exact 4-wide walk + the (tiny) binary launch for the rays it left over (non-finite 1/d).
-// `stage` 0 = subpath stage, 1 = connection stage: each has its own left-over list and stack-overflow region, since the
-// two run side by side in the sample pipeline.
+// One persistent launch of the exact 4-wide walk.  `stage` 0 = subpath stage, 1 = connection stage: each has its own
+// stack-overflow region, since the two run side by side in the sample pipeline.
 template <class Source>
 int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* count, unsigned* work_counter, Source src, int is_conn) {
     const int grid = stage == 0 ? persistent_grid_paths(r) : persistent_grid_conn(r);
     WideView w = r->wide;
     w.overflow = r->d_wide_ovf + (size_t)stage * persistent_grid() * BLOCK * WIDE_STACK_OVERFLOW;
-    w.leftover = r->d_leftover[stage];
-    w.leftover_count = r->d_leftover_count + stage;
-    HIP_TRY(r, hipMemsetAsync(w.leftover_count, 0, sizeof(unsigned), st));
     // LDS per workgroup: per-lane stack (8 B per entry and lane) + the top of the tree (128 B per wide node); experiment
     // switches: debug_flags bits 16-19 stack entries (0 = default), bits 20-23 window in units of 32 wide nodes
     const int sflag = (r->debug_flags >> 16) & 0xF, wflag = (r->debug_flags >> 20) & 0xF;
     w.stack_lds = sflag ? std::min(sflag, WIDE_STACK_LDS) : 4;
     w.n_lds_nodes = std::min(r->n_wide, 32 * (wflag ? wflag : 2));
     const size_t lds = (size_t)w.stack_lds * BLOCK * 8 + (size_t)w.n_lds_nodes * 128;
-    if (two_tris_per_step(r)) hipLaunchKernelGGL((k_traverse_wide<true, Source>), dim3(grid), dim3(BLOCK), lds, st, w, count, work_counter, src, r->d_stats, is_conn);
-    else hipLaunchKernelGGL((k_traverse_wide<false, Source>), dim3(grid), dim3(BLOCK), lds, st, w, count, work_counter, src, r->d_stats, is_conn);
-    HIP_TRY(r, hipGetLastError());
-    // left-over rays: the binary walk over the list (its own work counter: slot stage of d_leftover_count + 2)
-    Source rest = src;
-    rest.remap = w.leftover;
-    unsigned* work2 = r->d_leftover_count + 2 + stage;
-    HIP_TRY(r, hipMemsetAsync(work2, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL((k_traverse_persistent<false, false, Source>), dim3(64), dim3(BLOCK), bvh_lds_bytes(r), st, r->bvh, w.leftover_count,
-                       work2, rest, r->d_stats, -1);
+    // the binary records (lanes whose ray has a non-finite 1/d) come through the caches: no window for them
+    BvhView b = r->bvh;
+    b.n_lds_nodes = 0; b.lds_tris = 0;
+    if (two_tris_per_step(r)) hipLaunchKernelGGL((k_traverse_wide<true, Source>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn);
+    else hipLaunchKernelGGL((k_traverse_wide<false, Source>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn);
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;
 }
@@ -347,7 +336,7 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
         unsigned* c_out = r->d_qcount + end;
         if (split) {
             Timed t(r, ST_TRAVERSE_PATHS, st);
-            PathRaySource src{q_in, pb.P0 + (size_t)first * B, pb.P1 + (size_t)first * B, r->d_hit, nullptr};
+            PathRaySource src{q_in, pb.P0 + (size_t)first * B, pb.P1 + (size_t)first * B, r->d_hit};
             // the per-level subpath launches take the 4-wide walk while the sample pipeline runs: alone they are tail-bound and
             // gain nothing (glass 7.43 -> 7.56 ms), but beside the connection stage what counts is the work they put on
             // the machine (-20 % VALU): 12.43 -> 12.19 ms per sample on the glass scene, 15.38 -> 15.0 on the blob.
@@ -445,7 +434,7 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
         if (split_conn(r)) {
             HIP_TRY(r, hipMemsetAsync(r->d_work + 7, 0, sizeof(unsigned), st));
             ConnRaySource src{r->d_ctag, lp.P0, cp.P0, r->d_chit[cs],
-                              V3{r->cam.focal_point[0], r->cam.focal_point[1], r->cam.focal_point[2]}, B, nullptr};
+                              V3{r->cam.focal_point[0], r->cam.focal_point[1], r->cam.focal_point[2]}, B};
             if (wide_walk(r)) {
                 TRY(launch_wide(r, st, 1, r->d_qcount + 7, r->d_work + 7, src, 1));
             } else {
@@ -897,9 +886,6 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
         HIP_TRY(r, hipMemcpy(r->d_wide, h_wide.data(), h_wide.size() * sizeof(float4), hipMemcpyHostToDevice));
         const size_t lanes = (size_t)persistent_grid() * BLOCK;
         if (!r->d_wide_ovf) TRY(dev_alloc(r, &r->d_wide_ovf, 2 * lanes * WIDE_STACK_OVERFLOW));
-        if (!r->d_leftover[0]) TRY(dev_alloc(r, &r->d_leftover[0], (size_t)r->B));
-        if (!r->d_leftover[1]) TRY(dev_alloc(r, &r->d_leftover[1], (size_t)CONN_SLOTS * r->B));
-        if (!r->d_leftover_count) { TRY(dev_alloc(r, &r->d_leftover_count, (size_t)4)); HIP_TRY(r, hipMemset(r->d_leftover_count, 0, 4 * sizeof(unsigned))); }
         r->wide.nodes = r->d_wide; r->wide.tris = r->d_tris;
         r->wide.root_lo = make_float4(boxes[0].min[0], boxes[0].min[1], boxes[0].min[2], 0.0f);
         r->wide.root_hi = make_float4(boxes[0].max[0], boxes[0].max[1], boxes[0].max[2], 0.0f);
@@ -1424,19 +1410,13 @@ int cl2_probe_traverse(cl2_renderer* r, const void* rays_v, size_t n_rays, int32
         if (!ok) rc = fail(r, CL2_E_HIP, "probe upload failed");
     }
     if (rc == CL2_OK && r->traversal_mode == 5 && r->n_wide > 0 && !r->counting) {
-        // the probe through the exact 4-wide walk with its left-over list (rays with a non-finite 1/d go to the binary walk)
-        unsigned* d_left = nullptr;
-        rc = dev_alloc(r, &d_left, n_rays);
-        if (rc == CL2_OK && hipMemsetAsync(r->d_work, 0, sizeof(unsigned), r->stream) != hipSuccess) rc = fail(r, CL2_E_HIP, "probe memset failed");
+        // the probe through the exact 4-wide walk (rays with a non-finite 1/d take the binary walk inside it)
+        if (hipMemsetAsync(r->d_work, 0, sizeof(unsigned), r->stream) != hipSuccess) rc = fail(r, CL2_E_HIP, "probe memset failed");
         if (rc == CL2_OK) {
-            PathRaySource src{nullptr, d_o, d_d, d_h, nullptr};
-            unsigned* keep = r->d_leftover[0];
-            r->d_leftover[0] = d_left;
+            PathRaySource src{nullptr, d_o, d_d, d_h};
             rc = launch_wide(r, r->stream, 0, d_n, r->d_work, src, 0);
-            r->d_leftover[0] = keep;
             if (rc == CL2_OK) rc = drain(r);
         }
-        dev_free(r, d_left);
     } else if (rc == CL2_OK) {
         if (r->counting)
             hipLaunchKernelGGL(k_traverse_paths<true>, dim3(grid_for(n_rays)), dim3(BLOCK), bvh_lds_bytes(r), r->stream, r->bvh, (const int*)nullptr, d_n, d_o, d_d, d_h, r->d_stats);

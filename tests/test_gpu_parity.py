@@ -53,8 +53,8 @@ def test_generated_rays_bit_exact(scene_name, request, oracle_mod):
 @pytest.mark.parametrize("mode", [0, 5])
 def test_closest_hit_bit_exact(scene_name, mode, request, oracle_mod):
     """traverse_bvh alone: camera rays, light rays and axis-parallel rays (inv_direction = +-inf) -- through the
-    one-ray-per-lane kernel (mode 0), through the exact 4-wide walk (5: the axis-parallel rays must come back from its
-    left-over list, walked by the binary kernel, the others from the wide walk)."""
+    one-ray-per-lane kernel (mode 0) and through the exact 4-wide walk (5: the lanes of the axis-parallel rays run the
+    binary walk inside that launch, the others the wide walk)."""
     from clive2_amd import struct_types as st
     scene = request.getfixturevalue(scene_name)
     r, o = _pair(scene, oracle_mod)
