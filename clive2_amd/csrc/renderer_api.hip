@@ -241,7 +241,7 @@ inline bool wide_walk(const cl2_renderer* r) {
     if (r->n_wide <= 0 || r->counting) return false;
     if (r->traversal_mode == 5) return true;
     const size_t bytes = (size_t)r->bvh.n_nodes * 32 + (size_t)r->bvh.n_tris * 48;
-    return (r->traversal_mode == 0 || r->traversal_mode == 4) && !tree_in_lds(r) && bytes <= ((size_t)16 << 20);
+    return (r->traversal_mode == 0 || r->traversal_mode == 3 || r->traversal_mode == 4) && !tree_in_lds(r) && bytes <= ((size_t)16 << 20);
 }
 // Whole subpaths (light, then camera, all levels) in ONE persistent launch per sample (k_subpaths_persistent)
 // instead of a traversal + a bounce launch per level and kind: mode 4.  Measured at 1080p (ms per sample, serial order /
