@@ -255,7 +255,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mesh", action="store_true", help="skip the second (config-3 mesh) workload of the N=1 line")
-    ap.add_argument("--mesh-steps", type=int, default=48)
+    ap.add_argument("--mesh-steps", type=int, default=96)
     ap.add_argument("--debug-flags", type=int, default=0, help="performance experiments only (invalid renders)")
     ap.add_argument("--scene", default="cornell", choices=["cornell", "glass", "blob", "interior", "open"],
                     help="cornell = the BASELINE metric's workload (default); the others are the mesh configs "
