@@ -50,10 +50,10 @@ class Counters(C.Structure):
 class Organisation(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("tree_in_lds", "persistent_subpaths", "persistent_connections", "two_tris_per_step",
                                          "n_records", "n_lds_records", "n_top_renumbered", "lds_triangles",
-                                         "levels_per_launch", "paths_share", "pipeline_stages", "wide_connections", "wide_nodes", "pad")] + [("tree_bytes", C.c_int64)]
+                                         "levels_per_launch", "paths_share", "pipeline_stages", "wide_connections", "wide_nodes", "pruned_records")] + [("tree_bytes", C.c_int64)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 EXPORTS = [

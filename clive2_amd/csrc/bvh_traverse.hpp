@@ -37,6 +37,9 @@ struct BvhView {
     int n_tris;
     int n_lds_nodes;         // records staged in LDS (<= LDS_NODE_CAP)
     int lds_tris;            // 1: all triangles staged in LDS (n_tris <= LDS_TRI_CAP)
+    int n_fast_nodes;        // records of the pruned table (0: none); only for trees that are wholly staged
+    const float4* fast_nodes;   // the tree without the inner records whose test is not worth its cost (cl2_upload_scene):
+                                // same hits for rays with finite 1/d, fewer box tests
 };
 
 constexpr int LDS_NODE_CAP = 512;   // records in the LDS window: at most 512 * 32 B = 16 KB
@@ -49,6 +52,7 @@ constexpr int LEAF_PACK_MAX = 16;   // triangles per leaf record
 struct BvhLds {
     const float4* nodes;     // 2 float4 per staged record
     const float4* tris;      // 3 float4 per triangle (only when b.lds_tris)
+    const float4* fast_nodes;   // 2 float4 per record of the pruned table (only when b.n_fast_nodes)
 };
 
 // Cooperative copy of the staged part of the tree; every thread of the block must call it.
@@ -58,9 +62,11 @@ __device__ __forceinline__ void stage_bvh(BvhLds& s, const BvhView& b) {
     float4* tris = cl2_tree_lds + 2 * b.n_lds_nodes;
     const int nt = blockDim.x, t = threadIdx.x;
     for (int i = t; i < 2 * b.n_lds_nodes; i += nt) nodes[i] = b.nodes[i];
+    float4* fast = tris + (b.lds_tris ? 3 * b.n_tris : 0);
     if (b.lds_tris)
         for (int i = t; i < 3 * b.n_tris; i += nt) tris[i] = b.tris[i];
-    s.nodes = nodes; s.tris = tris;
+    for (int i = t; i < 2 * b.n_fast_nodes; i += nt) fast[i] = b.fast_nodes[i];
+    s.nodes = nodes; s.tris = tris; s.fast_nodes = fast;
     __syncthreads();
 }
 
@@ -77,13 +83,12 @@ struct Hit { int tri; float t, u, v; };
 //            the caller selects FAST_MINMAX only for waves whose rays all have finite 1/d.
 template <bool COUNT, bool ALL_LDS, bool FAST_MINMAX>
 __device__ __forceinline__ Hit closest_hit_impl(const BvhLds& s, const BvhView& b, V3 o, V3 d, V3 inv,
-                                               unsigned& n_box, unsigned& n_tri) {
+                                               unsigned& n_box, unsigned& n_tri, const float4* lds_nodes, int n_nodes) {
     Hit best{-1, __builtin_inff(), 0.0f, 0.0f};
     int node = 0;
-    const int n_nodes = b.n_nodes;
     while (node < n_nodes) {
         float4 lo, hi;
-        if (ALL_LDS || node < b.n_lds_nodes) { lo = s.nodes[2 * node]; hi = s.nodes[2 * node + 1]; }
+        if (ALL_LDS || node < b.n_lds_nodes) { lo = lds_nodes[2 * node]; hi = lds_nodes[2 * node + 1]; }
         else { lo = b.nodes[2 * node]; hi = b.nodes[2 * node + 1]; }
         int next = __float_as_int(lo.w);                   // skip: first record after this subtree
         if (COUNT) n_box++;
@@ -142,11 +147,13 @@ __device__ __forceinline__ Hit closest_hit(const BvhLds& s, const BvhView& b, V3
     const bool all_lds = b.lds_tris && b.n_nodes <= b.n_lds_nodes;
     const bool fast = __all(finite3(inv));
     if (all_lds) {
-        if (fast) return closest_hit_impl<COUNT, true, true>(s, b, o, d, inv, n_box, n_tri);
-        return closest_hit_impl<COUNT, true, false>(s, b, o, d, inv, n_box, n_tri);
+        // the pruned table: not while counting (the tallies are those of the full walk)
+        if (fast && !COUNT && b.n_fast_nodes) return closest_hit_impl<COUNT, true, true>(s, b, o, d, inv, n_box, n_tri, s.fast_nodes, b.n_fast_nodes);
+        if (fast) return closest_hit_impl<COUNT, true, true>(s, b, o, d, inv, n_box, n_tri, s.nodes, b.n_nodes);
+        return closest_hit_impl<COUNT, true, false>(s, b, o, d, inv, n_box, n_tri, s.nodes, b.n_nodes);
     }
-    if (fast) return closest_hit_impl<COUNT, false, true>(s, b, o, d, inv, n_box, n_tri);
-    return closest_hit_impl<COUNT, false, false>(s, b, o, d, inv, n_box, n_tri);
+    if (fast) return closest_hit_impl<COUNT, false, true>(s, b, o, d, inv, n_box, n_tri, s.nodes, b.n_nodes);
+    return closest_hit_impl<COUNT, false, false>(s, b, o, d, inv, n_box, n_tri, s.nodes, b.n_nodes);
 }
 
 }  // namespace cl2

@@ -71,6 +71,8 @@ struct cl2_renderer {
     // 4-wide collapse of the tree for the exact wide walk (bvh_wide.hpp); n_wide == 0: not available for this scene
     float4* d_wide = nullptr;
     int n_wide = 0;
+    int n_fast = 0;                      // records of the pruned table (bvh.n_fast_nodes unless debug_flags bit 7 switches it off)
+    float4* d_fast = nullptr;            // pruned record table of an LDS-resident tree (cl2_upload_scene); bvh.n_fast_nodes == 0: none
     WideView wide{};
     int2* d_wide_ovf = nullptr;          // per-lane stack overflow of the wide launches (one region per stage: [2])
     CameraRec cam{};
@@ -220,7 +222,7 @@ int launch_generate_both(cl2_renderer* r, hipStream_t st, const PathBufs* set) {
 // equal there (6.05 vs 6.00 Grays/s) and persistent wins from 82k triangles on (4.7 vs 3.9).
 // dynamic shared memory of a launch that stages the tree (stage_bvh)
 inline size_t bvh_lds_bytes(const cl2_renderer* r) {
-    return ((size_t)2 * r->bvh.n_lds_nodes + (r->bvh.lds_tris ? (size_t)3 * r->bvh.n_tris : 0)) * sizeof(float4);
+    return ((size_t)2 * r->bvh.n_lds_nodes + (r->bvh.lds_tris ? (size_t)3 * r->bvh.n_tris : 0) + (size_t)2 * r->bvh.n_fast_nodes) * sizeof(float4);
 }
 inline bool tree_in_lds(const cl2_renderer* r) { return r->bvh.lds_tris && r->bvh.n_nodes <= r->bvh.n_lds_nodes; }
 inline bool split_paths(const cl2_renderer* r) {
@@ -311,7 +313,7 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
     const size_t lds = (size_t)w.stack_lds * BLOCK * 8 + (size_t)w.n_lds_nodes * 128;
     // the binary records (lanes whose ray has a non-finite 1/d) come through the caches: no window for them
     BvhView b = r->bvh;
-    b.n_lds_nodes = 0; b.lds_tris = 0;
+    b.n_lds_nodes = 0; b.lds_tris = 0; b.n_fast_nodes = 0;
     if (two_tris_per_step(r)) hipLaunchKernelGGL((k_traverse_wide<true, Source>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn);
     else hipLaunchKernelGGL((k_traverse_wide<false, Source>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn);
     HIP_TRY(r, hipGetLastError());
@@ -754,6 +756,7 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     // native builder made, not guaranteed for hand-made Box[] arrays) and no leaf exceeds one record. ----
     std::vector<float4> h_wide;
     int n_wide = 0;
+    bool nests = false;
     {
         bool ok = n_boxes >= 3 && boxes[0].right == 0;
         auto inside = [&](const BoxRec& c, const BoxRec& p) {
@@ -765,6 +768,7 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
             if (b.right == 0) ok = inside(boxes[b.left], b) && inside(boxes[b.left + 1], b);
             else ok = (b.right - b.left) <= LEAF_PACK_MAX;
         }
+        nests = ok;
         if (ok) {
             // slots of reference box x in its visit order: child left+1 first, each inner child replaced by its children
             auto slots_of = [&](int x, int* out) {
@@ -832,6 +836,54 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
             }
         }
     }
+    // ---- pruned table for the LDS-resident walk.  For a ray with finite 1/d an inner box's test can only prune (same
+    // argument as the wide walk: a child that passes its test implies its parent passed), so an inner record may be
+    // dropped and its children visited unconditionally without changing any hit.  A record is dropped when the test is
+    // expected to cost more than it saves: (1 - area / area of the nearest tested ancestor) x cost of the subtree < 1
+    // box test, the surface-area estimate of the chance that a ray that reached the ancestor misses this box.  The
+    // Cornell box loses its root and its one other inner box (both span the room): 3 box tests per ray instead of 5.
+    // Rays with a non-finite 1/d, and the counting mode, walk the full table. ----
+    std::vector<float4> h_fast;
+    int n_fast = 0;
+    if (nests && n_top == 0 && n_records <= LDS_NODE_CAP && n_tris <= LDS_TRI_CAP) {
+        auto area = [&](const BoxRec& b) {
+            const double x = (double)b.max[0] - b.min[0], y = (double)b.max[1] - b.min[1], z = (double)b.max[2] - b.min[2];
+            return 2.0 * (x * y + y * z + z * x);
+        };
+        std::vector<double> cost(n_boxes, 0.0), anc_area(n_boxes, 0.0);
+        for (int i = n_boxes - 1; i >= 0; i--) {
+            const BoxRec& b = boxes[i];
+            cost[i] = b.right == 0 ? 1.0 + cost[b.left] + cost[b.left + 1] : 1.0 + 2.5 * (b.right - b.left);
+        }
+        std::vector<char> dropped((size_t)n_records + 1, 0);
+        anc_area[0] = area(boxes[0]);
+        for (int i = 0; i < n_boxes; i++) {
+            const BoxRec& b = boxes[i];
+            if (b.right != 0) continue;
+            const double a = area(b);
+            const double p_miss = anc_area[i] > 0.0 ? std::max(0.0, 1.0 - a / anc_area[i]) : 0.0;
+            const bool drop = p_miss * (cost[i] - 1.0) < 1.0;
+            dropped[rec_index[i]] = drop ? 1 : 0;
+            anc_area[b.left] = anc_area[b.left + 1] = drop ? anc_area[i] : a;
+        }
+        std::vector<int> fast_index((size_t)n_records + 1);
+        for (int k = 0; k <= n_records; k++) { fast_index[k] = n_fast; if (k < n_records && !dropped[k]) n_fast++; }
+        if (n_fast < n_records) {
+            h_fast.resize(2 * (size_t)n_fast);
+            for (int i = 0; i < n_boxes; i++) {
+                const int k = rec_index[i];
+                if (dropped[k]) continue;
+                float4 lo = h_nodes[2 * (size_t)k], hi = h_nodes[2 * (size_t)k + 1];
+                lo.w = as_f(fast_index[k + subtree[i]]);
+                if (boxes[i].right == 0) hi.w = as_f(~fast_index[k + 1]);
+                h_fast[2 * (size_t)fast_index[k]] = lo;
+                h_fast[2 * (size_t)fast_index[k] + 1] = hi;
+            }
+        } else {
+            n_fast = 0;
+        }
+    }
+
     for (int t = 0; t < n_tris; t++) {
         const TriRec& T = tris[t];
         // edge vectors: the same binary32 subtractions ray_triangle_intersect performs (trace.metal:118-119)
@@ -895,6 +947,14 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     r->bvh.n_nodes = n_records; r->bvh.n_tris = n_tris;
     r->bvh.n_lds_nodes = std::min(n_records, LDS_NODE_CAP);
     r->bvh.lds_tris = n_tris <= LDS_TRI_CAP ? 1 : 0;
+    dev_free(r, r->d_fast);
+    r->bvh.fast_nodes = nullptr; r->bvh.n_fast_nodes = 0;
+    if (n_fast > 0) {
+        TRY(dev_alloc(r, &r->d_fast, h_fast.size()));
+        HIP_TRY(r, hipMemcpy(r->d_fast, h_fast.data(), h_fast.size() * sizeof(float4), hipMemcpyHostToDevice));
+        r->bvh.fast_nodes = r->d_fast; r->bvh.n_fast_nodes = ((r->debug_flags >> 7) & 1) ? 0 : n_fast;
+    }
+    r->n_fast = n_fast;
     r->n_mats = n_mats; r->light_count = light_count; r->cam = cam;
     r->n_top = n_top;
     r->scene_ok = true;
@@ -1282,11 +1342,17 @@ int cl2_query_organisation(cl2_renderer* r, cl2_organisation* out) {
     out->paths_share = r->paths_share;
     out->pipeline_stages = pipeline_stages(r);
     out->wide_nodes = r->n_wide;
+    out->pruned_records = r->bvh.n_fast_nodes;
     out->wide_connections = (wide_walk(r) && split_conn(r)) ? 1 : 0;
     out->tree_bytes = (int64_t)r->bvh.n_nodes * 32 + (int64_t)r->bvh.n_tris * 48;
     return CL2_OK;
 }
-int cl2_set_debug_flags(cl2_renderer* r, int flags) { if (!r) return CL2_E_INVALID; r->debug_flags = flags; return CL2_OK; }
+int cl2_set_debug_flags(cl2_renderer* r, int flags) {
+    if (!r) return CL2_E_INVALID;
+    r->debug_flags = flags;
+    r->bvh.n_fast_nodes = ((flags >> 7) & 1) ? 0 : r->n_fast;      // bit 7: walk the full table (A/B of the pruned one)
+    return CL2_OK;
+}
 int cl2_set_counting(cl2_renderer* r, int on) { if (!r) return CL2_E_INVALID; r->counting = on != 0; return CL2_OK; }
 
 int cl2_read_counters(cl2_renderer* r, cl2_counters* out) {

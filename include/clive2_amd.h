@@ -192,7 +192,8 @@ typedef struct {
     int32_t pipeline_stages;        /* effective setting of cl2_set_pipelining */
     int32_t wide_connections;       /* connection rays walk the exact 4-wide collapse of the tree (csrc/bvh_wide.hpp) */
     int32_t wide_nodes;             /* nodes of that collapse (0: not available: hand-made boxes that do not nest, leaves above 16 triangles) */
-    int32_t pad;
+    int32_t pruned_records;         /* records of the pruned table of an LDS-resident tree (inner boxes whose test costs more than it saves are
+                                       dropped: exact for rays with finite 1/d); 0: none */
     int64_t tree_bytes;             /* 32 B per record + 48 B per intersection triangle */
 } cl2_organisation;
 int cl2_query_organisation(cl2_renderer* r, cl2_organisation* out);
@@ -211,7 +212,8 @@ int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
  * bits 16-19 stack entries per lane in LDS (0 = default 4), bits 20-23 LDS window in units of 32 wide nodes
  * (0 = default 2); whole-subpath launch (mode 4): bits 13-15 register budget as waves per SIMD (4, 5, 6;
  * 7 = 8; 0 = default 5), bits 16-22 lanes gathered before a wave runs its bounce phase (0 = default 32),
- * bits 24-30 steps a finished lane waits at most (0 = default 48). */
+ * bits 24-30 steps a finished lane waits at most (0 = default 48); bit 7 walks the full record table of an
+ * LDS-resident tree instead of the pruned one (cl2_organisation.pruned_records). */
 int cl2_set_debug_flags(cl2_renderer* r, int flags);
 int cl2_reset_counters(cl2_renderer* r);
 

@@ -539,6 +539,38 @@ def test_open_scene_paths_of_every_length(mode, levels, stages, oracle_mod):
     assert r.counters()["rays"] == o.rays_traced
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
+def test_pruned_table_is_equivalent(scene_name, mode, request, oracle_mod):
+    """LDS-resident trees are walked through a table without the inner boxes whose test is expected to cost more
+    than it saves (cl2_upload_scene: exact for rays with finite 1/d, the others walk the full table).  The Cornell
+    box keeps its 3 leaves of 5 boxes.  Same subpaths, seeds and image as the full table (debug bit 7) and the oracle."""
+    scene = request.getfixturevalue(scene_name)
+    r, o = _pair(scene, oracle_mod)
+    full, _ = _pair(scene, oracle_mod)
+    full.set_debug_flags(1 << 7)
+    org = r.organisation()
+    assert org["tree_in_lds"] == 1 and 0 < org["pruned_records"] < org["n_records"], org
+    if scene_name == "cornell_small":
+        assert (org["n_records"], org["pruned_records"]) == (5, 3)
+    assert full.organisation()["pruned_records"] == 0
+    r.set_traversal_mode(mode); full.set_traversal_mode(mode)
+    _run_to_paths(r, o)
+    full.make_light_rays(); full.make_camera_rays(); full.trace_light_rays(); full.trace_camera_rays()
+    for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
+        assert r.export_paths(which).tobytes() == ref.tobytes() == full.export_paths(which).tobytes()
+    _run_rest(r, o)
+    full.join_paths(); full.finalize_samples(); full.gather_light_image(); full.process_images()
+    r.run_samples(3); full.run_samples(3)
+    assert np.array_equal(r.get_random_buffer(), full.get_random_buffer())
+    assert r.read_accumulators()[3].tobytes() == full.read_accumulators()[3].tobytes()       # unidirectional image: no atomics
+    # the counting mode walks the full table: its tallies are those of the reference's walk
+    r.reset_counters(); r.set_counting(True); full.reset_counters(); full.set_counting(True)
+    r.run_samples(1); full.run_samples(1)
+    assert r.counters() == full.counters()
+    r.close(); full.close()
+
+
 @pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
 def test_wide_resolve_kernel_agrees(scene_name, request, oracle_mod):
     """The second implementation of the resolve stage (one wave per camera vertex, running total relayed
