@@ -53,7 +53,6 @@ struct BvhLds {
     const float4* nodes;     // 2 float4 per staged record
     const float4* tris;      // 3 float4 per triangle (only when b.lds_tris)
     const float4* fast_nodes;   // 2 float4 per record of the pruned table (only when b.n_fast_nodes)
-    const float* tri_z;         // third part of the staged triangle records (stage_bvh)
 };
 
 // Cooperative copy of the staged part of the tree; every thread of the block must call it.
@@ -64,51 +63,14 @@ __device__ __forceinline__ void stage_bvh(BvhLds& s, const BvhView& b) {
     const int nt = blockDim.x, t = threadIdx.x;
     for (int i = t; i < 2 * b.n_lds_nodes; i += nt) nodes[i] = b.nodes[i];
     float4* fast = tris + (b.lds_tris ? 3 * b.n_tris : 0);
-    if (b.lds_tris) {
-        // 36 of a record's 48 bytes are data: staged as {v0.xyz, e1.x}[n] {e1.yz, e2.xy}[n] {e2.z}[n], so that a test
-        // reads 2 x 16 + 4 bytes (18 LDS cycles per wave instead of 24 -- the LDS pipe is the second-busiest unit of
-        // the one-ray-per-lane kernels)
-        float* c = reinterpret_cast<float*>(cl2_tree_lds) + 4 * (2 * b.n_lds_nodes + 2 * b.n_tris);
-        s.tri_z = c;
-        for (int i = t; i < b.n_tris; i += nt) {
-            const float4 a0 = b.tris[3 * i], a1 = b.tris[3 * i + 1], a2 = b.tris[3 * i + 2];
-            tris[i] = make_float4(a0.x, a0.y, a0.z, a1.x);
-            tris[b.n_tris + i] = make_float4(a1.y, a1.z, a2.x, a2.y);
-            c[i] = a2.z;
-        }
-    }
+    if (b.lds_tris)
+        for (int i = t; i < 3 * b.n_tris; i += nt) tris[i] = b.tris[i];
     for (int i = t; i < 2 * b.n_fast_nodes; i += nt) fast[i] = b.fast_nodes[i];
     s.nodes = nodes; s.tris = tris; s.fast_nodes = fast;
     __syncthreads();
 }
 
-// triangle record i of the staged copy (layout: stage_bvh)
-__device__ __forceinline__ void lds_tri(const BvhLds& s, int n_tris, int i, float4& a0, float4& a1, float4& a2) {
-    const float4 p = s.tris[i], q = s.tris[n_tris + i];
-    const float z = s.tri_z[i];
-    a0 = make_float4(p.x, p.y, p.z, 0.0f);
-    a1 = make_float4(p.w, q.x, q.y, 0.0f);
-    a2 = make_float4(q.z, q.w, z, 0.0f);
-}
-
 struct Hit { int tri; float t, u, v; };
-
-// ray_triangle_intersect, trace.metal:117-142, against a pre-fetched record {v0, e1, e2}; keeps the hit on strict t < best.t
-__device__ __forceinline__ void tri_test(V3 o, V3 d, float4 a0, float4 a1, float4 a2, int index, Hit& best) {
-    const V3 e1 = v3(a1), e2 = v3(a2);
-    const V3 h = cross(d, e2);
-    const float f = rcp_exact(dot(e1, h));
-    const V3 sv = o - v3(a0);
-    const float u = f * dot(sv, h);
-    if (!(u < 0 || u > 1)) {
-        const V3 q = cross(sv, e1);
-        const float v = f * dot(d, q);
-        if (!(v < 0 || u + v > 1)) {
-            const float t = f * dot(e2, q);
-            if (t > DELTA_F && t < best.t) { best.tri = index; best.t = t; best.u = u; best.v = v; }
-        }
-    }
-}
 
 // Closest hit along (o, d) with inv = 1/d.
 //   COUNT    adds node/triangle test tallies.
@@ -150,7 +112,7 @@ __device__ __forceinline__ Hit closest_hit_impl(const BvhLds& s, const BvhView& 
                 const int left = info >> 4, right = left + (info & 15) + 1;
                 for (int i = left; i < right; i++) {   // trace.metal:161-172
                     float4 a0, a1, a2;
-                    if (ALL_LDS || b.lds_tris) lds_tri(s, b.n_tris, i, a0, a1, a2);
+                    if (ALL_LDS || b.lds_tris) { a0 = s.tris[3 * i]; a1 = s.tris[3 * i + 1]; a2 = s.tris[3 * i + 2]; }
                     else { a0 = b.tris[3 * i]; a1 = b.tris[3 * i + 1]; a2 = b.tris[3 * i + 2]; }
                     if (COUNT) n_tri++;
                     // ray_triangle_intersect, trace.metal:117-142
@@ -208,6 +170,23 @@ __device__ __forceinline__ Hit closest_hit(const BvhLds& s, const BvhView& b, V3
 // one global atomic per chunk), so all 64 lanes stay busy until the launch runs dry.  The sequence
 // of node visits, triangle tests and comparisons of each ray is exactly that of closest_hit_impl.
 namespace cl2 {
+
+// ray_triangle_intersect, trace.metal:117-142, against a pre-fetched record {v0, e1, e2}; keeps the hit on strict t < best.t
+__device__ __forceinline__ void tri_test(V3 o, V3 d, float4 a0, float4 a1, float4 a2, int index, Hit& best) {
+    const V3 e1 = v3(a1), e2 = v3(a2);
+    const V3 h = cross(d, e2);
+    const float f = rcp_exact(dot(e1, h));
+    const V3 sv = o - v3(a0);
+    const float u = f * dot(sv, h);
+    if (!(u < 0 || u > 1)) {
+        const V3 q = cross(sv, e1);
+        const float v = f * dot(d, q);
+        if (!(v < 0 || u + v > 1)) {
+            const float t = f * dot(e2, q);
+            if (t > DELTA_F && t < best.t) { best.tri = index; best.t = t; best.u = u; best.v = v; }
+        }
+    }
+}
 
 constexpr int RAY_CHUNK_MAX = 512;  // rays handed to a wave per global atomic: 64..512, about a quarter of a wave's fair share
 
@@ -299,8 +278,8 @@ __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhVi
                 tri_i = i1 + 1;
                 float4 a0, a1, a2, c0, c1, c2;
                 if (b.lds_tris) {
-                    lds_tri(s, b.n_tris, i0, a0, a1, a2);
-                    if (TWO_TRIS) lds_tri(s, b.n_tris, i1, c0, c1, c2);
+                    a0 = s.tris[3 * i0]; a1 = s.tris[3 * i0 + 1]; a2 = s.tris[3 * i0 + 2];
+                    if (TWO_TRIS) { c0 = s.tris[3 * i1]; c1 = s.tris[3 * i1 + 1]; c2 = s.tris[3 * i1 + 2]; }
                 } else {
                     a0 = b.tris[3 * i0]; a1 = b.tris[3 * i0 + 1]; a2 = b.tris[3 * i0 + 2];
                     if (TWO_TRIS) { c0 = b.tris[3 * i1]; c1 = b.tris[3 * i1 + 1]; c2 = b.tris[3 * i1 + 2]; }

@@ -188,7 +188,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_traverse_paths(
         BvhView bvh, const int* __restrict__ queue, const unsigned* __restrict__ count,
         const float4* __restrict__ P0v, const float4* __restrict__ P1v, float4* __restrict__ hit, Stats* stats) {
-    BvhLds lds{nullptr, nullptr, nullptr, nullptr};
+    BvhLds lds{nullptr, nullptr};
     stage_bvh(lds, bvh);
     const unsigned n = *count;
     const unsigned j = blockIdx.x * BLOCK + threadIdx.x;
@@ -261,7 +261,7 @@ template <bool COUNT, bool TWO_TRIS, class Source>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(78))) void k_traverse_persistent(BvhView bvh, const unsigned* __restrict__ count,
                                                               unsigned* __restrict__ work_counter, Source src, Stats* stats,
                                                               int is_conn) {
-    BvhLds lds{nullptr, nullptr, nullptr, nullptr};
+    BvhLds lds{nullptr, nullptr};
     stage_bvh(lds, bvh);
     const unsigned n = *count;
     unsigned nb = 0, nt = 0;
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_trace_subpath(
         const float4* __restrict__ ext_hit) {
     // EXT_HIT: the closest hits of the (single) level were produced by k_traverse_persistent (large
     // scenes: traversal with ray replacement runs as its own launch); the BVH is not staged here.
-    BvhLds lds{nullptr, nullptr, nullptr, nullptr};
+    BvhLds lds{nullptr, nullptr};
     __shared__ ShadeLds sh;
     const bool shade_lds = bvh.n_tris <= SHADE_LDS_CAP, mats_lds = n_mats <= LDS_MAT_CAP;
     if (shade_lds) for (int i = threadIdx.x; i < 4 * bvh.n_tris; i += BLOCK) sh.tri_shade[i] = tri_shade_g[i];
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
         BvhView bvh, WideView wide, int B, unsigned* __restrict__ work_counter, PathBufs lp, PathBufs cp, uint2* __restrict__ seeds,
         const float4* __restrict__ tri_shade_g, const MaterialDev* __restrict__ mats_g, int n_mats, Stats* stats,
         int bounce_lanes, int bounce_wait, int kinds /* 1 light subpaths only, 2 camera only, 3 both (light first) */) {
-    BvhLds s{nullptr, nullptr, nullptr, nullptr};
+    BvhLds s{nullptr, nullptr};
     BvhView b = bvh;
     // WIDE: LDS holds the top of the wide tree and the per-lane stacks instead of the binary window
     extern __shared__ float4 cl2_tree_lds[];
@@ -755,9 +755,9 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
                 const int i1 = two ? i0 + 1 : i0;
                 tri_i = i1 + 1;
                 float4 a0, a1, a2, c0, c1, c2;
-                if (!WIDE && b.lds_tris) {
-                    lds_tri(s, b.n_tris, i0, a0, a1, a2);
-                    if (TWO_TRIS) lds_tri(s, b.n_tris, i1, c0, c1, c2);
+                if (b.lds_tris) {
+                    a0 = s.tris[3 * i0]; a1 = s.tris[3 * i0 + 1]; a2 = s.tris[3 * i0 + 2];
+                    if (TWO_TRIS) { c0 = s.tris[3 * i1]; c1 = s.tris[3 * i1 + 1]; c2 = s.tris[3 * i1 + 2]; }
                 } else {
                     a0 = b.tris[3 * i0]; a1 = b.tris[3 * i0 + 1]; a2 = b.tris[3 * i0 + 2];
                     if (TWO_TRIS) { c0 = b.tris[3 * i1]; c1 = b.tris[3 * i1 + 1]; c2 = b.tris[3 * i1 + 2]; }
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_conn(
         BvhView bvh, int B, const unsigned* __restrict__ count, const int* __restrict__ ctag,
         const float4* __restrict__ LP0, const float4* __restrict__ CP0, CameraRec cam,
         float2* __restrict__ chit, Stats* stats) {
-    BvhLds lds{nullptr, nullptr, nullptr, nullptr};
+    BvhLds lds{nullptr, nullptr};
     stage_bvh(lds, bvh);
     const unsigned n = *count;
     const V3 focal = cam3(cam.focal_point);
