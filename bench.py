@@ -8,11 +8,16 @@ buffer); the accumulators are summed once with an in-place RCCL all-reduce (insi
 cl2_reduce_accumulators) inside the timed region.  One "ray" = one closest-hit BVH query
 (SURVEY.md §8d); rays are counted on the device.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--width 1920 --height 1080]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--width 1920 --height 1080] [--total-spp S]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Only RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are read from the launcher's environment: torch is
+`python bench.py --gpus N` with N > 1 and no launcher environment starts ITSELF as N rank processes (one per
+GPU: RANK / LOCAL_RANK / WORLD_SIZE and one shared CLIVE2_RENDEZVOUS_FILE in their environment) before anything
+touches the GPU -- the parent never loads the library -- waits for them, relays rank 0's JSON line and exits
+non-zero if any rank did.  Under an external launcher only RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are read
+from its environment.  Default is weak scaling (every rank renders K samples of the frame); `--total-spp S`
+splits a FIXED S samples over the ranks (strong scaling: configs 4 / 5 of BASELINE.json).  torch is
 not imported (the library runs on the ROCm runtime it was built for; barrier, max-over-ranks clock
 and ray tally go through cl2_comm_allreduce_f64).  Rank 0 prints ONE JSON line.
 
@@ -25,7 +30,9 @@ Instruction counts and HBM bytes per launch come from committed rocprofv3 PMC pa
 marked "static" (used only while the kernel sources still hash to what was profiled).
 `roofline_mesh` is the same launch on the config-3 mesh scene (tree in L2, not LDS), where the
 formula is a memory statement: its bytes are priced against the L2's aggregate bandwidth when the
-tree fits the 32 MiB of L2 (bound "l2"), against HBM otherwise (bound "hbm": --scene interior).  `cpu_baseline` times the C oracle (CPU restatement of the
+tree fits the 32 MiB of L2 (bound "l2"); `roofline_hbm` is the config-5 stand-in (1M triangles, 155 MB
+tree: bound "hbm", 8 TB/s).  The stage-share tuner of the mesh scenes (cl2_tune) runs in the warm-up,
+never inside the clock.  `cpu_baseline` times the C oracle (CPU restatement of the
 reference's kernels, OpenMP over host cores) on a bounded sample.
 """
 import argparse
@@ -47,25 +54,38 @@ L2_BYTES = 32 << 20
 VALU_PEAK_GINST = 1024 * 2.4e9 / 2.0 / 1e9
 
 
-def cpu_baseline(width, height, samples):
+def cpu_baseline(width, height, samples, repeats=2):
     """Oracle (kind 'port'): the CPU restatement of trace.metal's kernels + renderer.py's host glue,
-    timed end to end on this host's cores.  Checker code used as the reported baseline only."""
-    # a GPU box exposes all host threads but grants a 16-CPU share: size the OpenMP team to it
-    os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
+    timed end to end on this host's cores.  Checker code used as the reported baseline only.  The OpenMP team is
+    sized to the box's CPU share (16 on a one-GPU box) and PINNED (one thread per core, spread): unpinned, the same
+    binary measured 26 and 43 Mrays/s on two boxes.  Best of `repeats` runs; every run is reported."""
+    try:
+        n_aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n_aff = os.cpu_count() or 1
+    threads = max(1, min(n_aff, 16))
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
     import clive2_amd as c2
     from oracle import oracle as orc
     orc.build()
     scene = c2.create_scene_from_preset("empty", width, height)
-    o = orc.OracleRenderer(scene, seeds=orc.make_seeds(width * height))
-    t0 = time.perf_counter()
-    for _ in range(samples):
-        o.run_sample()
-    dt = time.perf_counter() - t0
+    runs, rays = [], 0
+    for _ in range(max(1, repeats)):
+        o = orc.OracleRenderer(scene, seeds=orc.make_seeds(width * height))
+        t0 = time.perf_counter()
+        for _ in range(samples):
+            o.run_sample()
+        dt = time.perf_counter() - t0
+        rays = o.rays_traced
+        runs.append(round(rays / dt / 1e6, 3))
     threads = int(os.environ["OMP_NUM_THREADS"])
-    return {"value": round(o.rays_traced / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"Cornell box {width}x{height}, {samples} sample(s) of the full BDPT pipeline "
-                      f"({o.rays_traced} rays, {dt:.1f} s; C oracle, OpenMP)"}
+    return {"value": max(runs), "unit": "Mrays/s", "cores": threads, "kind": "port", "runs": runs,
+            "threads_pinned": f"OMP_PROC_BIND={os.environ['OMP_PROC_BIND']} OMP_PLACES={os.environ['OMP_PLACES']}, {n_aff} CPUs in the affinity mask",
+            "sample": f"Cornell box {width}x{height}, {samples} sample(s) of the full BDPT pipeline per run "
+                      f"({rays} rays; C oracle, OpenMP, best of {len(runs)} runs)"}
 
 
 def kernel_sources_sha():
@@ -79,21 +99,22 @@ def kernel_sources_sha():
 
 
 def static_pmc(scene, W, H):
-    """Per-launch PMC figures of the connection-ray traversal kernel from profiles/r02_pmc_<scene>.json
+    """Per-launch PMC figures of the connection-ray traversal kernel from profiles/r<NN>_pmc_<scene>.json
     (tools/profile_round.sh + tools/profile_summaries.py: rocprofv3 --pmc passes of this same command), or
     None when there is no summary for this scene / frame size, or the kernel sources have changed since
     it was taken."""
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_{scene}.json")
-    try:
-        d = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    if d.get("sources_sha") != kernel_sources_sha() or (d.get("width"), d.get("height")) != (W, H):
-        return None
-    row = d.get("kernels", {}).get(d.get("conn_traversal_kernel"))
-    if not row:
-        return None
-    return dict(row, source=f"profiles/r02_pmc_{scene}.json", sources_sha=d["sources_sha"])
+    sha = kernel_sources_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{scene}.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("sources_sha") != sha or (d.get("width"), d.get("height")) != (W, H):
+            continue
+        row = d.get("kernels", {}).get(d.get("conn_traversal_kernel"))
+        if row:
+            return dict(row, source=os.path.relpath(path, ROOT), sources_sha=d["sources_sha"])
+    return None
 
 
 def build_scene(name, W, H):
@@ -125,8 +146,8 @@ def build_scene(name, W, H):
 
 
 def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world, with_comm):
-    """Warm-up (+ counting pass), the timed region, a serial per-stage breakdown.  Returns the pieces
-    of the JSON line that depend on the workload."""
+    """Warm-up (tuner + counting pass), the timed region, a serial per-stage breakdown.  `steps` = samples THIS
+    rank renders inside the clock.  Returns the pieces of the JSON line that depend on the workload."""
     import clive2_amd as c2  # noqa: F401
     from clive2_amd import _native
     from clive2_amd.renderer import Renderer, make_seeds
@@ -148,8 +169,12 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
     r.set_levels_per_launch(args.levels_per_launch)
     r.set_traversal_mode(args.traversal_mode)
     r.set_pipelining(args.pipelining)
+    if args.debug_flags:
+        r.set_debug_flags(args.debug_flags)      # launch-organisation switches only: the library refuses the invalid-render bits
 
-    # untimed: warm-up (also the counting pass that measures N_node / N_tri per ray)
+    # untimed: the measured launch-organisation choices (bounces per launch of a small scene, stage shares of a large one:
+    # cl2_tune, 1 / 30 real samples), then the counting pass that measures N_node / N_tri per ray
+    tuned = r.tune()
     r.set_counting(True)
     r.run_samples(max(warmup, 1))
     cw = r.counters()
@@ -161,8 +186,7 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
     r.reset_counters()
     r.reset_accumulators()
     r.set_profiling(1)               # timed region: HIP events around the connection-ray traversal launch only
-    if args.debug_flags:
-        r.set_debug_flags(args.debug_flags)
+    org_before = r.organisation()
 
     barrier()
     t0 = time.perf_counter()
@@ -174,11 +198,12 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
 
     c = r.counters()
     r_org = r.organisation()
+    assert r_org["paths_share"] == org_before["paths_share"], "a tuning experiment ran inside the timed region"
     rays_local = c["rays"]
     # untimed: per-stage breakdown (HIP events around every launch) over a few more samples, in serial
     # order on one stream -- with the sample pipeline on, spans of the two streams overlap and a
     # stage's span includes whatever ran beside it
-    n_break = min(steps, 8)
+    n_break = max(1, min(steps, 8))
     r.reset_counters()
     r.set_profiling(2)
     r.set_pipelining(0)
@@ -187,19 +212,19 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
     r.set_profiling(0)
     r.set_pipelining(args.pipelining)
     if with_comm:
-        rays_total = r.allreduce_host([float(rays_local)], op="sum")[0]
+        rays_total, steps_total = r.allreduce_host([float(rays_local), float(steps)], op="sum")
         dt = r.allreduce_host([dt], op="max")[0]
     else:
-        rays_total = float(rays_local)
+        rays_total, steps_total = float(rays_local), float(steps)
 
     out = None
     if rank == 0:
         import numpy as np
         img, wts, cnt, _ = r.read_accumulators()
         # after the reduce every rank holds the sums of all ranks (and the breakdown pass added n_break samples)
-        assert np.isfinite(img).all() and (cnt >= steps * world).all(), "accumulators corrupt"
+        assert np.isfinite(img).all() and (cnt >= int(steps_total)).all(), "accumulators corrupt"
         # cl2_upload_scene stages the whole tree in LDS up to 512 records and 512 triangles
-        in_lds = len(scene.triangles) <= 512 and len(scene.boxes) <= 512
+        in_lds = bool(r_org["tree_in_lds"])
         org = r_org
         persistent = bool(org["persistent_connections"])
         k_name = ("k_traverse_wide<ConnRaySource>" if org["wide_connections"] else "k_traverse_persistent<ConnRaySource>") if persistent \
@@ -213,22 +238,26 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
         alg_gbs_alone = (cb["rays_traverse_conn"] / max(cb["launches_traverse_conn"], 1)) * b_ray / max(alone_ms * 1e-3, 1e-12) / 1e9
         pmc = static_pmc(scene_name, W, H)
         traffic = pmc.get("hbm_bytes") if pmc else None
+        lanes = pmc.get("thread_cycles_per_valu_inst") if pmc else None     # average active lanes per VALU wave-instruction
         hbm = {"algorithmic_gbs": round(alg_gbs, 1), "algorithmic_gbs_launch_alone": round(alg_gbs_alone, 1),
                "bytes_per_ray": round(b_ray, 1), "n_node": round(n_node, 3), "n_tri": round(n_tri, 3),
                "measured_gbs": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic and avg_ms > 0 else None,
                "measured_frac_of_peak": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_ms > 0 else None,
                "peak_gbs": HBM_PEAK_GBS}
         common = {"kernel": k_name, "rays_per_launch": round(rays_per_launch), "avg_launch_ms": round(avg_ms, 4),
-                  "avg_launch_ms_alone": round(alone_ms, 4), "traffic": traffic,
-                  "static": {"what": "traffic and wave_insts_per_launch (rocprofv3 PMC passes of this command, committed)",
+                  "avg_launch_ms_alone": round(alone_ms, 4), "traffic": traffic, "active_lanes_per_valu_inst": lanes,
+                  "static": {"what": "traffic, wave_insts_per_launch, active lanes (rocprofv3 PMC passes of this command, committed)",
                              "source": pmc["source"], "sources_sha": pmc["sources_sha"]} if pmc else None}
         if in_lds:
             # tree and triangles staged in LDS: the launch is bound by VALU issue, not by HBM
             n_valu = pmc.get("SQ_INSTS_VALU") if pmc else None
             ach = n_valu / (avg_ms * 1e-3) / 1e9 if n_valu and avg_ms > 0 else None
+            frac = ach / VALU_PEAK_GINST if ach else None
             roof = {"bound": "valu", "achieved": round(ach, 1) if ach else None, "peak": round(VALU_PEAK_GINST, 1),
-                    "unit": "G wave-instructions/s", "frac": round(ach / VALU_PEAK_GINST, 4) if ach else None,
+                    "unit": "G wave-instructions/s", "frac": round(frac, 4) if frac else None,
                     "frac_launch_alone": round(n_valu / (alone_ms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4) if n_valu and alone_ms > 0 else None,
+                    # the issue fraction counts instructions, not lanes: weighted by the lanes that were active in them
+                    "lane_weighted_frac": round(frac * lanes / 64.0, 4) if frac and lanes else None,
                     "wave_insts_per_launch": n_valu, "cycles_per_wave_inst": 2.0, "hbm": hbm}
         else:
             # the tree is read through the caches: the algorithmic bytes are a memory statement.  Against which level: a tree
@@ -241,9 +270,108 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
                     "tree_bytes": org["tree_bytes"], "hbm": hbm}
         roof.update(common)
         out = {"scene_desc": scene_desc, "rays_total": rays_total, "rays_local": rays_local, "dt": dt, "roofline": roof,
+               "steps_total": int(steps_total), "tuner_samples_in_warmup": tuned, "paths_share": org["paths_share"],
                "stages": {k[3:]: round(cb[k] / n_break, 4) for k in cb if k.startswith("ms_")}}
     r.close()
     return out
+
+
+# ---------------------------------------------------------------- N > 1 without an external launcher
+def dry_child(rank, local_rank, world):
+    """`--dry-spawn`: what a rank process does up to the communicator bootstrap, without a GPU (CPU tests of the
+    self-spawn path): the id hand-over through the shared rendezvous file with 128 random bytes standing in for
+    ncclUniqueId.  Rank 0 prints one JSON line describing what every rank saw."""
+    import hashlib as hl
+    from clive2_amd.distributed import exchange_unique_id, finish_exchange, rendezvous_path
+    if rank == int(os.environ.get("CLIVE2_BENCH_DRY_FAIL_RANK", "-1")):
+        print(f"[rank {rank}] dry-spawn: failing on request", file=sys.stderr)
+        sys.exit(3)
+    path = rendezvous_path()
+    uid = exchange_unique_id(rank, world, lambda: os.urandom(128), 128, timeout=60.0)
+    me = {"rank": rank, "local_rank": local_rank, "world": world, "pid": os.getpid(), "ppid": os.getppid(),
+          "id_sha": hl.sha256(uid).hexdigest()[:16], "rendezvous": path,
+          "explicit_file": os.environ.get("CLIVE2_RENDEZVOUS_FILE")}
+    tmp = f"{path}.seen{rank}.tmp"
+    with open(tmp, "w") as f:
+        json.dump(me, f)
+    os.replace(tmp, f"{path}.seen{rank}")
+    if rank != 0:
+        return
+    seen, deadline = {}, time.monotonic() + 60.0
+    while len(seen) < world and time.monotonic() < deadline:
+        for k in range(world):
+            if k not in seen and os.path.exists(f"{path}.seen{k}"):
+                seen[k] = json.load(open(f"{path}.seen{k}"))
+        time.sleep(0.01)
+    for k in seen:
+        os.unlink(f"{path}.seen{k}")
+    finish_exchange(0)
+    print(json.dumps({"dry_spawn": True, "n_gpus": world, "ranks": [seen[k] for k in sorted(seen)],
+                      "ids_equal": len({v["id_sha"] for v in seen.values()}) == 1 and len(seen) == world}), flush=True)
+
+
+def spawn_ranks(n, argv, timeout):
+    """The parent of `python bench.py --gpus N` (N > 1, no launcher environment).  It makes NO GPU / HIP call and never
+    loads the library: it starts N fresh processes of this script (one per GPU) with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* and ONE shared CLIVE2_RENDEZVOUS_FILE (a fresh name: no stale file can exist), waits, relays rank 0's
+    stdout (the JSON line) and returns the first non-zero exit code (after ending the other ranks), else 0."""
+    import secrets
+    import socket
+    import subprocess
+    import tempfile
+    import threading
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    rdv = os.path.join(tempfile.gettempdir(), f"clive2_bench_id_{os.getuid()}_{os.getpid()}_{secrets.token_hex(8)}")
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CLIVE2_RENDEZVOUS_FILE=rdv,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        # rank 0's stdout is the job's stdout (one JSON line); the other ranks' goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr, stdin=subprocess.DEVNULL))
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc, deadline = 0, time.monotonic() + timeout
+    live = set(range(n))
+    while live and rc == 0:
+        for k in sorted(live):
+            code = procs[k].poll()
+            if code is None:
+                continue
+            live.discard(k)
+            if code != 0:
+                print(f"bench.py: rank {k} exited with {code}; ending the other ranks", file=sys.stderr)
+                rc = code if code > 0 else 1
+                break
+        if rc == 0 and live and time.monotonic() > deadline:
+            print(f"bench.py: ranks {sorted(live)} still running after {timeout:.0f} s; ending them", file=sys.stderr)
+            rc = 124
+        if rc == 0 and live:
+            time.sleep(0.05)
+    if rc != 0:
+        for k in live:                      # exactly the processes started above, by pid
+            procs[k].terminate()
+        t_kill = time.monotonic() + 10.0
+        for k in live:
+            try:
+                procs[k].wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                procs[k].kill()
+                procs[k].wait()
+    reader.join(timeout=10.0)
+    for leftover in glob.glob(rdv + "*"):
+        try:
+            os.unlink(leftover)
+        except OSError:
+            pass
+    if rc == 0:
+        sys.stdout.write(b"".join(chunks).decode(errors="replace"))
+        sys.stdout.flush()
+    return rc
 
 
 def main():
@@ -251,12 +379,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--total-spp", type=int, default=0,
+                    help="strong scaling: a FIXED number of samples split over the ranks (samples_for_rank) instead of --steps per rank")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-mesh", action="store_true", help="skip the second (config-3 mesh) workload of the N=1 line")
-    ap.add_argument("--mesh-steps", type=int, default=96)
-    ap.add_argument("--debug-flags", type=int, default=0, help="performance experiments only (invalid renders)")
+    ap.add_argument("--no-mesh", action="store_true", help="skip the mesh workloads (config 3 and config 5 stand-ins) of the N=1 line")
+    ap.add_argument("--mesh-steps", type=int, default=64)
+    ap.add_argument("--hbm-steps", type=int, default=24)
+    ap.add_argument("--debug-flags", type=int, default=0, help="launch-organisation switches (include/clive2_amd.h); results unchanged")
     ap.add_argument("--scene", default="cornell", choices=["cornell", "glass", "blob", "interior", "open"],
                     help="cornell = the BASELINE metric's workload (default); the others are the mesh configs "
                          "(SURVEY 8d C3-C5 stand-ins), for profiling only")
@@ -266,16 +397,23 @@ def main():
     ap.add_argument("--cpu-width", type=int, default=1920)
     ap.add_argument("--cpu-height", type=int, default=1080)
     ap.add_argument("--cpu-samples", type=int, default=4)
+    ap.add_argument("--spawn-timeout", type=float, default=1500.0, help="self-spawned ranks are ended after this many seconds")
+    ap.add_argument("--dry-spawn", action="store_true", help="rank processes stop after the id hand-over and need no GPU (CPU test of the self-spawn path)")
     args = ap.parse_args()
+    if args.debug_flags & 7:
+        sys.exit("bench.py: debug bits 0-2 skip parts of the resolve stage (invalid renders); they exist only in the test "
+                 "variant of the library and are refused here")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: become the launcher, before anything touches the GPU
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.spawn_timeout))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be started as one process per GPU with RANK/LOCAL_RANK/WORLD_SIZE set "
-                     "(e.g. python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...)")
-        args.gpus = world
+    args.gpus = world
+    if args.dry_spawn:
+        return dry_child(rank, local_rank, world)
     if not os.path.exists("/dev/kfd"):
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # RCCL refuses two ranks on one device, so a one-GPU box cannot rehearse N > 1; CLIVE2_BENCH_FORCE_COMM=1 (rehearsal
@@ -283,33 +421,48 @@ def main():
     # cl2_comm_allreduce_f64, the all-reduce inside the timed region -- on a one-rank communicator.
     W, H = args.width, args.height
     with_comm = world > 1 or os.environ.get("CLIVE2_BENCH_FORCE_COMM") == "1"
-    res = run_workload(args, args.scene, W, H, args.steps, args.warmup, rank, local_rank, world, with_comm=with_comm)
+    strong = args.total_spp > 0
+    if strong:
+        from clive2_amd.distributed import samples_for_rank
+        my_steps = samples_for_rank(args.total_spp, rank, world)
+    else:
+        my_steps = args.steps
+    res = run_workload(args, args.scene, W, H, my_steps, args.warmup, rank, local_rank, world, with_comm=with_comm)
 
     if rank == 0:
+        steps_out = args.total_spp if strong else args.steps
         out = {
             "metric": "Mrays/sec (whole node) + HBM GB/s, 1080p Cornell box, 1/2/4/8 MI355X",
             "value": round(res["rays_total"] / res["dt"] / 1e6, 2),
             "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(res["dt"] / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "n_gpus": world, "steps": steps_out, "warmup": args.warmup,
+            # weak: every rank renders `steps` samples side by side; strong: `steps` samples in all, split over the ranks
+            "ms_per_step": round(res["dt"] / steps_out * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{res['scene_desc']} {W}x{H}, BDPT{' diffuse-only' if args.scene == 'cornell' else ''}, "
-                                   f"{args.steps} spp per GPU", "width": W, "height": H,
-                       "rays_per_pixel_sample": round(res["rays_local"] / (args.steps * W * H), 3),
+                                   + (f"{args.total_spp} spp in all, split over {world} GPU(s)" if strong else f"{args.steps} spp per GPU"),
+                       "width": W, "height": H,
+                       "rays_per_pixel_sample": round(res["rays_total"] / (res["steps_total"] * W * H), 3),
+                       "samples_rendered_all_ranks": res["steps_total"],
                        "parallelism": f"sample-split x{world}, one in-place RCCL all-reduce of the accumulators"
                                       if with_comm else "one GPU (no collective)"},
             "roofline": res["roofline"],
             "stage_ms_per_step_serial": res["stages"],
         }
         if world == 1 and not args.no_mesh and args.scene == "cornell":
-            # second workload of the same line: the config-3 mesh scene, where the tree (1,781 boxes, 5,136
-            # triangles) is read through the caches and the bytes formula is a memory statement
-            m = run_workload(args, "glass", W, H, args.mesh_steps, 4, 0, local_rank, 1, with_comm=False)
-            out["roofline_mesh"] = dict(m["roofline"], workload=f"{m['scene_desc']} {W}x{H}, {args.mesh_steps} spp",
-                                        mrays_per_s=round(m["rays_total"] / m["dt"] / 1e6, 2),
-                                        ms_per_step=round(m["dt"] / args.mesh_steps * 1e3, 3),
-                                        stage_ms_per_step_serial=m["stages"])
+            # two more workloads on the same line, where the tree is read through the caches and the bytes formula is a
+            # memory statement: config 3 (1,781 boxes / 5,136 triangles: L2-resident -> bound "l2") and config 5 (338 k
+            # boxes / 1 M triangles, 155 MB -> bound "hbm").  Their stage-share tuner runs in the warm-up (cl2_tune).
+            for key, name, n_steps in (("roofline_mesh", "glass", args.mesh_steps), ("roofline_hbm", "interior", args.hbm_steps)):
+                t_setup = time.perf_counter()
+                m = run_workload(args, name, W, H, n_steps, 2, 0, local_rank, 1, with_comm=False)
+                out[key] = dict(m["roofline"], workload=f"{m['scene_desc']} {W}x{H}, {n_steps} spp",
+                                mrays_per_s=round(m["rays_total"] / m["dt"] / 1e6, 2),
+                                ms_per_step=round(m["dt"] / n_steps * 1e3, 3),
+                                tuner_samples_in_warmup=m["tuner_samples_in_warmup"], paths_share=m["paths_share"],
+                                leg_wall_s=round(time.perf_counter() - t_setup, 1),
+                                stage_ms_per_step_serial=m["stages"])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_width, args.cpu_height, args.cpu_samples)
         print(json.dumps(out), flush=True)

@@ -25,6 +25,7 @@ struct RcclApi {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string error;
 };
@@ -48,6 +49,7 @@ inline RcclApi* rccl_api(std::string& why) {
         CL2_SYM(CommDestroy, "ncclCommDestroy");
         CL2_SYM(CommAbort, "ncclCommAbort");
         CL2_SYM(AllReduce, "ncclAllReduce");
+        CL2_SYM(CommGetAsyncError, "ncclCommGetAsyncError");
         CL2_SYM(GetErrorString, "ncclGetErrorString");
 #undef CL2_SYM
     });

@@ -146,7 +146,12 @@ __device__ __forceinline__ void resolve_pair(
         if (S > 1) new_light_f = div_pi(__builtin_fabsf(dot(dir_l_to_c, lds_v3(LNs, S - 1))));
         const V3 mcol = v3(mats[a.meta & 0xFF].color_type);
         const float shade = new_light_f * Gj / p_s;
-        if (light_pixel_idx >= 0 && light_pixel_idx < B && !(debug_flags & 1)) {
+#ifdef CL2_TEST_VARIANT
+        const bool splat_on = !(debug_flags & 1);          // timing dissection (test variant only): no splat = invalid render
+#else
+        const bool splat_on = true;
+#endif
+        if (light_pixel_idx >= 0 && light_pixel_idx < B && splat_on) {
             const V3 c = ((w * shade) * prior_color) * mcol;
             // Splat {c.xyz, w} into light_image[pixel] (float4).  The lanes that reach this point
             // exchange their 4 values through a per-wave LDS table so that four CONSECUTIVE lanes
@@ -285,8 +290,10 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
         hits[0] = make_float2(0.0f, 0.0f);
 #pragma unroll
         for (int s = 1; s <= MAX_VERTS; s++) hits[s] = chit_load(chit, B, t, s, pid);
-        if ((debug_flags & 2) && t >= 2) continue;      // experiment switches: skip the t >= 2 / t == 1 pairs
+#ifdef CL2_TEST_VARIANT
+        if ((debug_flags & 2) && t >= 2) continue;      // timing dissection (test variant only): skip the t >= 2 / t == 1 pairs
         if ((debug_flags & 4) && t == 1) continue;
+#endif
 #define CL2_PAIR(S)                                                                                             \
         if ((S) <= Ll && t + (S) >= 2)                                                                          \
             resolve_pair<S>(t, B, pid, lv, GL, RL, l_spec, c_spec, spec7, c_o, c_n, cP0.w, cP1.w, cP3.w, c_cos, \

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <limits>
 #include <chrono>
 #include <string>
@@ -19,6 +20,7 @@
 #include "kernels.hpp"
 #include "bvh_builder.hpp"
 #include "comm_rccl.hpp"
+#include "comm_wait.hpp"
 
 using namespace cl2;
 
@@ -55,6 +57,7 @@ struct cl2_renderer {
     bool scene_ok = false, counting = false;
     int profiling = 0;                   // 0 off, 1 the connection-ray traversal launch only, 2 every stage
     int debug_flags = 0;
+    int gather_lanes = 32, gather_wait = 48;   // whole-subpath launch: lanes gathered / steps waited before a wave runs its bounce phase
     int traversal_mode = 0;              // 0 auto, 1 fused (one ray per lane), 2 split (persistent traversal + ray replacement)
     unsigned* d_work = nullptr;          // [8] work counters of the persistent traversal launches
     int levels_per_launch = 0;           // subpath levels per launch (6 = one launch, 1 = compaction after every bounce, 0 = by survival)
@@ -107,6 +110,7 @@ struct cl2_renderer {
     // multi-GPU sample split: one RCCL communicator per handle (cl2_comm_init_rank)
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_nranks = 0;
+    bool comm_poisoned = false;          // a collective failed or timed out (or the host said so): tear down with ncclCommAbort
     double* d_comm_scratch = nullptr;    // [COMM_SCRATCH] doubles for cl2_comm_allreduce_f64
 };
 
@@ -310,6 +314,8 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
     const int sflag = (r->debug_flags >> 16) & 0xF, wflag = (r->debug_flags >> 20) & 0xF;
     w.stack_lds = sflag ? std::min(sflag, WIDE_STACK_LDS) : 4;
     w.n_lds_nodes = std::min(r->n_wide, 32 * (wflag ? wflag : 2));
+    // never more than the 64 KB a workgroup may ask for: the window gives way, the stack entries are needed
+    w.n_lds_nodes = std::min<int>(w.n_lds_nodes, (int)(((size_t)64 * 1024 - (size_t)w.stack_lds * BLOCK * 8) / 128));
     const size_t lds = (size_t)w.stack_lds * BLOCK * 8 + (size_t)w.n_lds_nodes * 128;
     // the binary records (lanes whose ray has a non-finite 1/d) come through the caches: no window for them
     BvhView b = r->bvh;
@@ -382,16 +388,13 @@ int launch_subpaths(cl2_renderer* r, hipStream_t st, const PathBufs* set, int ki
     }
     HIP_TRY(r, hipMemsetAsync(r->d_work, 0, sizeof(unsigned), st));
     Timed t(r, ST_TRAVERSE_PATHS, st);
-    // lanes gathered / steps waited before a wave runs its bounce phase (debug_flags bits 16-22 / 24-30 override)
-    const int lanes = ((r->debug_flags >> 16) & 0x7F) ? ((r->debug_flags >> 16) & 0x7F) : 32;
-    const int wait = ((r->debug_flags >> 24) & 0x7F) ? ((r->debug_flags >> 24) & 0x7F) : 48;
+    // lanes gathered / steps waited before a wave runs its bounce phase (cl2_set_subpath_gather)
+    const int lanes = r->gather_lanes, wait = r->gather_wait;
     // the exact 4-wide walk inside the launch where the scene has it (same rule as the connection rays)
     const bool widew = wide_walk(r) && two_tris_per_step(r);
     WideView w = r->wide;
-    const int sflag = (r->debug_flags >> 16) & 0xF, wflag = (r->debug_flags >> 20) & 0xF;
     w.stack_lds = 4; w.n_lds_nodes = 0;
     if (widew) {
-        (void)sflag; (void)wflag;
         w.n_lds_nodes = std::min(r->n_wide, 64);
         w.overflow = r->d_wide_ovf;                            // stage 0 region: the subpath stage
     }
@@ -1063,50 +1066,73 @@ int run_chunk(cl2_renderer* r, bool pipe, int count) {
 }
 }  // namespace
 
+namespace {
+// The automatic choices that need measurements of the scene.  Both render real samples (every candidate
+// organisation gives identical results), `done` counts them.
+//
+// Small scenes, levels_per_launch = 0: one whole-subpath launch keeps a wave busy as long as its
+// longest path lives.  In a closed scene that is every path (6.0 rays per subpath: nothing to gain,
+// compaction costs 35 %); in an open scene most paths leave after a bounce or two and a wave idles on
+// its last survivor.  The first sample of a scene tells which: below 4 rays per subpath the walk is cut
+// into launches of 2 bounces with the survivors compacted in between (open test scene: 2.02 -> 1.62 ms).
+int tune_levels(cl2_renderer* r, int& done) {
+    if (split_paths(r) || r->levels_per_launch != 0 || r->levels_auto != 0) return CL2_OK;
+    unsigned long long before = 0, after = 0;
+    TRY(subpath_ray_tally(r, &before));
+    TRY(run_chunk(r, false, 1));
+    TRY(subpath_ray_tally(r, &after));
+    done += 1;
+    r->levels_auto = (double)(after - before) < 4.0 * 2.0 * (double)r->B ? 2 : (int)MAX_VERTS;
+    return CL2_OK;
+}
+// Large scenes: how the two stages share the machine while the pipeline runs.  Persistent launches hold
+// their wave slots until they run dry, so the stages get fixed shares (persistent_grid_paths/_conn) -- 3, 4
+// or 5 eighths for the subpath stage, no fixed shares, or the serial order.  The best choice depends on the
+// scene and the frame size; every candidate renders TUNE_SAMPLES samples and is timed on the host.
+constexpr int TUNE_TOTAL = 5 * TUNE_SAMPLES;
+inline bool shares_untuned(const cl2_renderer* r) { return pipeline_stages(r) != 0 && split_conn(r) && r->paths_share == 0; }
+int tune_shares(cl2_renderer* r, int& done) {
+    if (!shares_untuned(r)) return CL2_OK;
+    int best = 4;
+    double best_t = 1e300;
+    for (int e : {3, 4, 5, 8, SHARE_SERIAL}) {
+        r->paths_share = e;
+        const auto t0 = std::chrono::steady_clock::now();
+        TRY(run_chunk(r, e != SHARE_SERIAL, TUNE_SAMPLES));
+        const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        done += TUNE_SAMPLES;
+        if (t < best_t) { best_t = t; best = e; }
+    }
+    r->paths_share = best;
+    return CL2_OK;
+}
+}  // namespace
+
 int cl2_run_samples(cl2_renderer* r, int n) {
     STAGE_PROLOGUE(r);
     if (n < 0) return fail(r, CL2_E_INVALID, "negative sample count");
     bool pipe = pipeline_stages(r) != 0 && n > 1;
     int done = 0;
-    // Small scenes, levels_per_launch = 0: one whole-subpath launch keeps a wave busy as long as its
-    // longest path lives.  In a closed scene that is every path (6.0 rays per subpath: nothing to gain,
-    // compaction costs 35 %); in an open scene most paths leave after a bounce or two and a wave idles on
-    // its last survivor.  The first sample of a scene tells which: below 4 rays per subpath the walk is cut
-    // into launches of 2 bounces with the survivors compacted in between (open test scene: 2.02 -> 1.62 ms).
-    if (!split_paths(r) && r->levels_per_launch == 0 && r->levels_auto == 0 && n >= 2) {
-        unsigned long long before = 0, after = 0;
-        TRY(subpath_ray_tally(r, &before));
-        TRY(run_chunk(r, false, 1));
-        TRY(subpath_ray_tally(r, &after));
-        done = 1;
-        r->levels_auto = (double)(after - before) < 4.0 * 2.0 * (double)r->B ? 2 : (int)MAX_VERTS;
-    }
-    // Large scenes, first long call: how the two stages share the machine while the pipeline runs.
-    // Persistent launches hold their wave slots until they run dry, so the stages get fixed shares
-    // (persistent_grid_paths/_conn) -- 3, 4 or 5 eighths for the subpath stage, no fixed shares, or the
-    // serial order.  The best choice depends on the scene and the frame size; every candidate renders
-    // the same samples.
-    auto timed_chunk = [&](bool pipelined, int count, double& seconds) -> int {
-        const auto t0 = std::chrono::steady_clock::now();
-        TRY(run_chunk(r, pipelined, count));
-        seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        done += count;
-        return CL2_OK;
-    };
-    const bool long_call = n - done >= 6 * TUNE_SAMPLES + 6;
-    if (pipe && split_conn(r) && r->paths_share == 0 && long_call) {
-        int best = 4;
-        double best_t = 1e300;
-        for (int e : {3, 4, 5, 8, SHARE_SERIAL}) {
-            r->paths_share = e;
-            double t = 0;
-            TRY(timed_chunk(e != SHARE_SERIAL, TUNE_SAMPLES, t));
-            if (t < best_t) { best_t = t; best = e; }
-        }
-        r->paths_share = best;
-    }
+    if (n >= 2) TRY(tune_levels(r, done));
+    // the share tuner runs inside the first LONG call of a scene (its 30 samples are part of the call's n) unless
+    // cl2_tune() ran it before
+    if (pipe && n - done >= TUNE_TOTAL + TUNE_SAMPLES + 6) TRY(tune_shares(r, done));
     if (pipe && split_conn(r) && r->paths_share == SHARE_SERIAL) pipe = false;
     return run_chunk(r, pipe, n - done);
+}
+
+/* Makes the measured choices of the launch organisation NOW instead of inside the first (long) cl2_run_samples
+ * call: the levels-per-launch probe of a small scene (1 sample) and the stage-share tuner of a large one (30
+ * samples).  The samples are real ones -- they advance the seeds and add to the accumulators exactly as the same
+ * number of run_sample iterations would -- and *samples_rendered says how many there were.  A benchmark calls
+ * this in its warm-up so that no timing experiment runs inside its clock. */
+int cl2_tune(cl2_renderer* r, int* samples_rendered) {
+    STAGE_PROLOGUE(r);
+    int done = 0;
+    TRY(tune_levels(r, done));
+    TRY(tune_shares(r, done));
+    if (samples_rendered) *samples_rendered = done;
+    return CL2_OK;
 }
 
 int cl2_set_pipelining(cl2_renderer* r, int on) {
@@ -1209,22 +1235,99 @@ int cl2_comm_init_rank(cl2_renderer* r, int nranks, int rank, const void* unique
     ncclComm_t comm = nullptr;
     RCCL_TRY(r, api, api->CommInitRank(&comm, nranks, id, rank));
     r->comm = comm; r->comm_rank = rank; r->comm_nranks = nranks;
+    r->comm_poisoned = false;
     return CL2_OK;
 }
 
+namespace {
+// Deadline for one collective (seconds): CLIVE2_COMM_TIMEOUT_S, default 300.  Ranks reach the reduce at
+// different times (scene set-up, sample counts that differ by one), so the default is generous; what it
+// bounds is the wait for a rank that will never come.
+double comm_deadline_seconds() {
+    if (const char* e = std::getenv("CLIVE2_COMM_TIMEOUT_S")) {
+        char* end = nullptr;
+        const double v = std::strtod(e, &end);
+        if (end != e && v > 0.0) return v;
+    }
+    return 300.0;
+}
+
+// Tear the communicator down without waiting for anybody: ncclCommAbort ends kernels of it that are still
+// spinning on a peer and frees its resources.  Used after a failed / timed-out collective and whenever the
+// handle goes away in a failed state -- a clean ncclCommDestroy would itself wait for outstanding work.
+void comm_abort(cl2_renderer* r, RcclApi* api) {
+    if (!r->comm) return;
+    ncclComm_t comm = r->comm;
+    r->comm = nullptr; r->comm_nranks = 0; r->comm_rank = 0;
+    if (api && api->CommAbort) (void)api->CommAbort(comm);
+}
+
+// Wait for the collective just enqueued on r->stream: polls the stream and the communicator's asynchronous
+// error state under the deadline (comm_wait.hpp).  On any failure the communicator is aborted and the
+// handle keeps the reason; the caller returns CL2_E_COMM and the process is expected to exit non-zero.
+int comm_wait(cl2_renderer* r, RcclApi* api, const char* what) {
+    int detail = 0;
+    const double deadline = comm_deadline_seconds();
+    const WaitResult res = wait_collective(
+        [&]() -> int {
+            const hipError_t e = hipStreamQuery(r->stream);
+            return e == hipSuccess ? 0 : (e == hipErrorNotReady ? 1 : -(int)e);
+        },
+        [&]() -> int {
+            ncclResult_t ae = ncclSuccess;
+            if (!api->CommGetAsyncError || api->CommGetAsyncError(r->comm, &ae) != ncclSuccess) return 0;
+            return (ae == ncclSuccess || ae == ncclInProgress) ? 0 : (int)ae;
+        },
+        deadline, &detail);
+    if (res == WAIT_DONE) return CL2_OK;
+    std::string why = std::string(what) + ": ";
+    if (res == WAIT_TIMEOUT) why += "not complete after " + std::to_string((int)deadline) + " s (a rank never joined the collective?); communicator aborted";
+    else if (res == WAIT_ASYNC_ERROR) why += std::string("asynchronous RCCL error: ") + api->GetErrorString((ncclResult_t)detail) + "; communicator aborted";
+    else why += std::string("stream error: ") + hipGetErrorString((hipError_t)(-detail)) + "; communicator aborted";
+    r->comm_poisoned = true;
+    comm_abort(r, api);
+    r->err = why;
+    return CL2_E_COMM;
+}
+
+// every failure between "communicator exists" and "collective complete" poisons the communicator: the peers are
+// (or will be) inside the collective and this rank will not complete it
+#define COMM_HIP_TRY(r, api, expr)                                                                 \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (r)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                         \
+            (r)->comm_poisoned = true; comm_abort((r), (api));                                    \
+            return CL2_E_HIP;                                                                     \
+        }                                                                                         \
+    } while (0)
+#define COMM_RCCL_TRY(r, api, expr)                                                                \
+    do {                                                                                          \
+        ncclResult_t e_ = (expr);                                                                 \
+        if (e_ != ncclSuccess) {                                                                  \
+            (r)->err = std::string(#expr) + ": " + (api)->GetErrorString(e_);                     \
+            (r)->comm_poisoned = true; comm_abort((r), (api));                                    \
+            return CL2_E_COMM;                                                                    \
+        }                                                                                         \
+    } while (0)
+}  // namespace
+
 /* The collective of SURVEY.md 8e: in place, on the stream every accumulating kernel ran on (drained
- * first: with the sample pipeline the accumulation runs on stream_res). */
+ * first: with the sample pipeline the accumulation runs on stream_res).  The wait for it has a deadline
+ * (comm_wait): a rank that never joins makes this call fail with CL2_E_COMM instead of blocking for ever. */
 int cl2_reduce_accumulators(cl2_renderer* r) {
     if (!r) return CL2_E_INVALID;
-    if (!r->comm) return fail(r, CL2_E_STATE, "no communicator (call cl2_comm_init_rank first)");
+    if (!r->comm) return fail(r, CL2_E_STATE, r->comm_poisoned ? "the communicator was aborted after a failed collective" : "no communicator (call cl2_comm_init_rank first)");
     std::string why;
     RcclApi* api = rccl_api(why);
     if (!api) return fail(r, CL2_E_COMM, why);
-    HIP_TRY(r, hipSetDevice(r->device));
-    TRY(drain(r));
-    RCCL_TRY(r, api, api->AllReduce(r->d_acc, r->d_acc, 8 * (size_t)r->B, ncclFloat, ncclSum, r->comm, r->stream));
-    HIP_TRY(r, hipStreamSynchronize(r->stream));
-    return CL2_OK;
+    COMM_HIP_TRY(r, api, hipSetDevice(r->device));
+    {
+        const int rc = drain(r);
+        if (rc != CL2_OK) { r->comm_poisoned = true; comm_abort(r, api); return rc; }
+    }
+    COMM_RCCL_TRY(r, api, api->AllReduce(r->d_acc, r->d_acc, 8 * (size_t)r->B, ncclFloat, ncclSum, r->comm, r->stream));
+    return comm_wait(r, api, "cl2_reduce_accumulators");
 }
 
 /* n <= 16 host doubles, summed (op 0) or maximised (op 1) over the ranks, in place: barrier, the
@@ -1232,16 +1335,33 @@ int cl2_reduce_accumulators(cl2_renderer* r) {
 int cl2_comm_allreduce_f64(cl2_renderer* r, double* values, int n, int op) {
     if (!r || !values) return CL2_E_INVALID;
     if (n < 1 || n > COMM_SCRATCH || (op != 0 && op != 1)) return fail(r, CL2_E_INVALID, "allreduce_f64: 1..16 values, op 0 (sum) or 1 (max)");
-    if (!r->comm) return fail(r, CL2_E_STATE, "no communicator (call cl2_comm_init_rank first)");
+    if (!r->comm) return fail(r, CL2_E_STATE, r->comm_poisoned ? "the communicator was aborted after a failed collective" : "no communicator (call cl2_comm_init_rank first)");
     std::string why;
     RcclApi* api = rccl_api(why);
     if (!api) return fail(r, CL2_E_COMM, why);
-    HIP_TRY(r, hipSetDevice(r->device));
-    TRY(drain(r));
-    HIP_TRY(r, hipMemcpyAsync(r->d_comm_scratch, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, r->stream));
-    RCCL_TRY(r, api, api->AllReduce(r->d_comm_scratch, r->d_comm_scratch, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, r->comm, r->stream));
-    HIP_TRY(r, hipMemcpyAsync(values, r->d_comm_scratch, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    COMM_HIP_TRY(r, api, hipSetDevice(r->device));
+    {
+        const int rc = drain(r);
+        if (rc != CL2_OK) { r->comm_poisoned = true; comm_abort(r, api); return rc; }
+    }
+    COMM_HIP_TRY(r, api, hipMemcpyAsync(r->d_comm_scratch, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, r->stream));
+    COMM_RCCL_TRY(r, api, api->AllReduce(r->d_comm_scratch, r->d_comm_scratch, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, r->comm, r->stream));
+    TRY(comm_wait(r, api, "cl2_comm_allreduce_f64"));
+    HIP_TRY(r, hipMemcpy(values, r->d_comm_scratch, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return CL2_OK;
+}
+
+/* The host's way of saying "this rank failed, do not wait for anybody": the communicator is torn down with
+ * ncclCommAbort at once, so peers blocked in a collective with this rank see an error or their own deadline
+ * instead of waiting for a rank that is about to exit.  Harmless without a communicator. */
+int cl2_comm_abort(cl2_renderer* r) {
+    if (!r) return CL2_E_INVALID;
+    if (!r->comm) return CL2_OK;
+    std::string why;
+    RcclApi* api = rccl_api(why);
+    (void)hipSetDevice(r->device);
+    r->comm_poisoned = true;
+    comm_abort(r, api);
     return CL2_OK;
 }
 
@@ -1252,7 +1372,9 @@ int cl2_comm_destroy(cl2_renderer* r) {
     RcclApi* api = rccl_api(why);
     if (!api) return fail(r, CL2_E_COMM, why);
     (void)hipSetDevice(r->device);
-    (void)drain(r);                       // nothing of ours may be in flight on the communicator's stream
+    // a handle whose own streams are in an error state, or whose last collective failed, must not wait in
+    // ncclCommDestroy for work that will never finish
+    if (r->comm_poisoned || drain(r) != CL2_OK) { comm_abort(r, api); return CL2_OK; }
     ncclComm_t comm = r->comm;
     r->comm = nullptr; r->comm_nranks = 0; r->comm_rank = 0;
     RCCL_TRY(r, api, api->CommDestroy(comm));
@@ -1349,8 +1471,21 @@ int cl2_query_organisation(cl2_renderer* r, cl2_organisation* out) {
 }
 int cl2_set_debug_flags(cl2_renderer* r, int flags) {
     if (!r) return CL2_E_INVALID;
+#ifndef CL2_TEST_VARIANT
+    // bits 0-2 switch parts of the resolve stage OFF (timing dissection: the render is invalid); they exist only in
+    // the test variant of the library and cannot be reached from the shipped one
+    if (flags & 7) return fail(r, CL2_E_INVALID, "debug bits 0-2 (skip parts of the resolve stage: invalid renders) exist only in the test variant of the library");
+#endif
+    if (flags & ~CL2_DEBUG_KNOWN_BITS) return fail(r, CL2_E_INVALID, "unknown debug flag bits (see include/clive2_amd.h)");
     r->debug_flags = flags;
     r->bvh.n_fast_nodes = ((flags >> 7) & 1) ? 0 : r->n_fast;      // bit 7: walk the full table (A/B of the pruned one)
+    return CL2_OK;
+}
+int cl2_set_subpath_gather(cl2_renderer* r, int lanes, int wait_steps) {
+    if (!r) return CL2_E_INVALID;
+    if (lanes < 0 || lanes > 64 || wait_steps < 0 || wait_steps > 1000) return fail(r, CL2_E_INVALID, "subpath gather: 0..64 lanes (0 = default 32), 0..1000 steps (0 = default 48)");
+    r->gather_lanes = lanes ? lanes : 32;
+    r->gather_wait = wait_steps ? wait_steps : 48;
     return CL2_OK;
 }
 int cl2_set_counting(cl2_renderer* r, int on) { if (!r) return CL2_E_INVALID; r->counting = on != 0; return CL2_OK; }

@@ -6,29 +6,56 @@ this module holds the host side of it: the rank environment, the sample partitio
 of RCCL's unique id from rank 0 to the other ranks of the node through a file.  torch is not needed.
 """
 import os
+import stat
 import tempfile
 import time
 
 import numpy as np
 
+_T_IMPORT = time.time()          # close to this rank's process start: files older than that (minus slack) belong to another job
+_STALE_SLACK_S = 120.0           # ranks of one job start within this of each other (sequential spawners, slow first imports)
+
 
 def rendezvous_path():
     """Where rank 0 leaves the communicator id for the other ranks of this job (one node).
     `CLIVE2_RENDEZVOUS_FILE` names it explicitly (any process spawner); otherwise it is derived from what
-    all ranks of one launch share and no other launch does: MASTER_ADDR/MASTER_PORT, the launcher's
-    run id and the launcher's pid (the ranks' common parent under `python -m torch.distributed.run`)."""
+    all ranks of one launch ATTEMPT share and no other does: MASTER_ADDR/MASTER_PORT, the launcher's run id, its
+    restart count (a torchrun restart keeps port, run id and pid) and the launcher's pid (the ranks' common
+    parent under `python -m torch.distributed.run`).  `bench.py --gpus N` (self-spawn) passes a fresh random name."""
     explicit = os.environ.get("CLIVE2_RENDEZVOUS_FILE")
     if explicit:
         return explicit
     key = "_".join(str(x) for x in (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
-                                    os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid(), os.getuid()))
+                                    os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                                    os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), os.getppid(), os.getuid()))
     return os.path.join(os.environ.get("CLIVE2_RENDEZVOUS_DIR", tempfile.gettempdir()), f"clive2_rccl_id_{key}")
 
 
+def _read_id(path, n_bytes):
+    """The id file, or None when it is not (yet) acceptable: it must be a regular file of this user (no symlink is
+    followed: the default directory is shared), exactly `n_bytes` long, and not older than this process (minus the
+    start-up slack) -- a file left behind by a crashed attempt with the same name predates us."""
+    try:
+        fd = os.open(path, os.O_RDONLY | os.O_NOFOLLOW)
+    except OSError:
+        return None
+    try:
+        st = os.fstat(fd)
+        if not stat.S_ISREG(st.st_mode) or st.st_uid != os.getuid() or st.st_size != n_bytes:
+            return None
+        if st.st_mtime < _T_IMPORT - _STALE_SLACK_S:
+            return None
+        uid = os.read(fd, n_bytes + 1)
+        return uid if len(uid) == n_bytes else None
+    finally:
+        os.close(fd)
+
+
 def exchange_unique_id(rank, world_size, make_id, n_bytes, path=None, timeout=180.0):
-    """Rank 0 calls `make_id()` (-> `n_bytes` bytes) and publishes them atomically (write + rename);
-    the others poll for the file.  Returns the id on every rank.  Rank 0 removes the file with
-    `finish_exchange` once every rank has joined the communicator (comm_init returns only then)."""
+    """Rank 0 calls `make_id()` (-> `n_bytes` bytes) and publishes them atomically (exclusive create of a private
+    temporary, mode 0600, then rename); the others poll for the file (`_read_id`).  Returns the id on every rank.
+    Rank 0 removes the file with `finish_exchange` once every rank has joined the communicator (comm_init returns
+    only then)."""
     path = path or rendezvous_path()
     if world_size == 1:
         return make_id()
@@ -37,21 +64,22 @@ def exchange_unique_id(rank, world_size, make_id, n_bytes, path=None, timeout=18
         if len(uid) != n_bytes:
             raise ValueError(f"unique id has {len(uid)} bytes, expected {n_bytes}")
         tmp = f"{path}.tmp{os.getpid()}"
-        with open(tmp, "wb") as f:
-            f.write(uid)
-        os.replace(tmp, path)
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
+        try:
+            os.write(fd, uid)
+        finally:
+            os.close(fd)
+        os.replace(tmp, path)              # also replaces whatever a dead attempt left under this name
         return uid
     deadline = time.monotonic() + timeout
     while True:
-        try:
-            # a file left behind by a crashed job with the same key would be much older than this process
-            if time.time() - os.path.getmtime(path) < 600.0:
-                with open(path, "rb") as f:
-                    uid = f.read()
-                if len(uid) == n_bytes:
-                    return uid
-        except OSError:
-            pass
+        uid = _read_id(path, n_bytes)
+        if uid is not None:
+            return uid
         if time.monotonic() > deadline:
             raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout:.0f} s (is rank 0 alive?)")
         time.sleep(0.02)

@@ -63,6 +63,7 @@ class Renderer:
     # ---- plumbing ----
     def _check(self, rc, what):
         if rc != 0:
+            self._failed = True          # close() then aborts the communicator instead of waiting for peers
             msg = self._L.cl2_last_error(self._h)
             raise RendererError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
 
@@ -224,6 +225,10 @@ class Renderer:
     def comm_destroy(self):
         self._check(self._L.cl2_comm_destroy(self._h), "cl2_comm_destroy")
 
+    def comm_abort(self):
+        """This rank failed: tear the communicator down without waiting for the others (ncclCommAbort)."""
+        self._L.cl2_comm_abort(self._h)
+
     def synchronize(self):
         self._check(self._L.cl2_synchronize(self._h), "cl2_synchronize")
 
@@ -260,7 +265,20 @@ class Renderer:
         self._check(self._L.cl2_set_traversal_mode(self._h, int(mode)), "set_traversal_mode")
 
     def set_debug_flags(self, flags):
+        """Launch-organisation switches (include/clive2_amd.h); none changes a result.  The shipped library
+        refuses bits 0-2 (they skip parts of the resolve stage and exist only in the test variant)."""
         self._check(self._L.cl2_set_debug_flags(self._h, int(flags)), "set_debug_flags")
+
+    def set_subpath_gather(self, lanes=0, wait_steps=0):
+        """Whole-subpath launch: lanes gathered / steps waited before a wave runs its bounce phase (0 = default)."""
+        self._check(self._L.cl2_set_subpath_gather(self._h, int(lanes), int(wait_steps)), "set_subpath_gather")
+
+    def tune(self):
+        """Make the measured launch-organisation choices now (cl2_tune); returns the number of (real) samples it rendered."""
+        n = C.c_int(0)
+        self._check(self._L.cl2_tune(self._h, C.byref(n)), "cl2_tune")
+        self.samples += n.value
+        return n.value
 
     def counters(self):
         c = Counters()
@@ -337,6 +355,8 @@ class Renderer:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            if getattr(self, "_failed", False):
+                self._L.cl2_comm_abort(self._h)
             self._L.cl2_destroy(self._h)
             self._h = C.c_void_p()
 

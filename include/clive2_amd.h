@@ -113,6 +113,13 @@ int cl2_finalize_samples(cl2_renderer* r);
 int cl2_gather_light_image(cl2_renderer* r);
 int cl2_process_images(cl2_renderer* r);
 int cl2_run_samples(cl2_renderer* r, int n);
+/* Two launch-organisation choices are MEASURED on the scene: bounces per launch for LDS-resident scenes (1 sample)
+ * and the share of the machine each pipeline stage gets on large scenes (5 candidates x 6 samples).  By default they
+ * are made inside the first cl2_run_samples call that is long enough (>= 2 / >= 42 samples); cl2_tune makes them now.
+ * Its samples are real ones (seeds advance, accumulators grow, exactly as that many run_sample iterations would);
+ * *samples_rendered (may be NULL) says how many.  Benchmarks call it in their warm-up.  No reference counterpart
+ * (src/renderer.py:281-291 is one fixed launch sequence). */
+int cl2_tune(cl2_renderer* r, int* samples_rendered);
 
 /* Subpath levels (bounces) traced per launch: 6 walks a whole subpath in one launch with its state in
  * registers; 1 compacts the survivors after every bounce (pays when most paths die early: open
@@ -164,7 +171,8 @@ int cl2_write_accumulators_packed(cl2_renderer* r, const float* host_src, size_t
  *      all   :  cl2_comm_init_rank(r, nranks, rank, id)      (collective: returns when all have called)
  *               ... cl2_run_samples(r, n_rank) ...
  *               cl2_reduce_accumulators(r)                  (collective; every rank then holds the sums)
- *               cl2_comm_destroy(r)                         (also done by cl2_destroy) -- */
+ *               cl2_comm_destroy(r)                         (also done by cl2_destroy)
+ *    failure:   cl2_comm_abort(r) on the rank that failed; the others get CL2_E_COMM from the collective -- */
 int cl2_device_count(void);                          /* HIP devices visible to this process (0 on error) */
 int cl2_synchronize(cl2_renderer* r);                /* drains the handle's streams, then the device */
 int cl2_comm_unique_id_bytes(void);
@@ -175,6 +183,13 @@ int cl2_reduce_accumulators(cl2_renderer* r);
  * whole-job ray tally, error-flag agreement before the collective */
 int cl2_comm_allreduce_f64(cl2_renderer* r, double* values, int n, int op);
 int cl2_comm_destroy(cl2_renderer* r);
+/* No collective blocks for ever: the wait for an enqueued all-reduce polls the stream and ncclCommGetAsyncError under
+ * a deadline (CLIVE2_COMM_TIMEOUT_S seconds, default 300); on a timeout or an asynchronous error the communicator is
+ * torn down with ncclCommAbort and the call returns CL2_E_COMM (the handle stays usable for local work, its
+ * communicator is gone).  A rank that fails locally calls cl2_comm_abort before it exits, so that its peers do not
+ * have to wait for their deadline; cl2_comm_destroy / cl2_destroy abort instead of destroying when the handle is in
+ * a failed state. */
+int cl2_comm_abort(cl2_renderer* r);
 
 /* How the library organises the launches for the uploaded scene (all organisations give identical results;
  * this is what the automatic choices of cl2_set_traversal_mode / _levels_per_launch / _pipelining came to). */
@@ -202,19 +217,25 @@ int cl2_query_organisation(cl2_renderer* r, cl2_organisation* out);
 int cl2_set_profiling(cl2_renderer* r, int level);  /* HIP-event timers: 0 off, 1 the connection-ray traversal launch only, 2 every stage */
 int cl2_set_counting(cl2_renderer* r, int on);      /* node / triangle test tallies in the traversal kernels */
 int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
-/* performance-experiment switches.  Bits 0-2 make the result an INVALID render: bit 0 skips the t=1
- * light-image splat atomics, bit 1 / bit 2 skip the t >= 2 / t == 1 strategy pairs in the resolve kernel.
- * The others only change the launch organisation (same results): bits 4-6 variant of the resolve
- * kernel (2 / 4: register budget; 7: one wave per camera vertex -- only in the test variant of the library,
- * libclive2_amd_test.so, built with -DCL2_TEST_VARIANT); bits 8-10 eighths of the wave slots given to the subpath stage while the sample
- * pipeline runs on a large scene (0 = tuned); bit 12 inverts the one/two-triangles-per-step choice of
- * the persistent walk; bit 3 sends the per-level subpath launches through the 4-wide walk too; 4-wide walk:
- * bits 16-19 stack entries per lane in LDS (0 = default 4), bits 20-23 LDS window in units of 32 wide nodes
- * (0 = default 2); whole-subpath launch (mode 4): bits 13-15 register budget as waves per SIMD (4, 5, 6;
- * 7 = 8; 0 = default 5), bits 16-22 lanes gathered before a wave runs its bounce phase (0 = default 32),
- * bits 24-30 steps a finished lane waits at most (0 = default 48); bit 7 walks the full record table of an
- * LDS-resident tree instead of the pruned one (cl2_organisation.pruned_records). */
+/* Launch-organisation switches for experiments and tests.  None of them changes a result.
+ *   bit 3       the per-level subpath launches take the 4-wide walk in the serial order too
+ *   bits 4-6    variant of the resolve kernel: 2 / 4 = register budget as waves per SIMD; 7 = one wave per camera
+ *               vertex (second implementation, only in the test variant of the library)
+ *   bit 7       walk the full record table of an LDS-resident tree instead of the pruned one
+ *   bits 8-10   eighths of the wave slots given to the subpath stage while the sample pipeline runs (0 = tuned)
+ *   bit 12      invert the one/two-triangles-per-step choice of the persistent walk
+ *   bits 13-15  whole-subpath launch: register budget as waves per SIMD (4, 5, 6; 7 = 8; 0 = default)
+ *   bits 16-19  4-wide walk: stack entries per lane in LDS (0 = default 4)
+ *   bits 20-23  4-wide walk: LDS window in units of 32 wide nodes (0 = default 2)
+ * Any other bit is refused (CL2_E_INVALID).  Bits 0-2 exist ONLY in the test variant of the library
+ * (libclive2_amd_test.so, -DCL2_TEST_VARIANT), where they switch parts of the resolve stage off for timing
+ * dissections -- bit 0 the t = 1 splat atomics, bit 1 / bit 2 the t >= 2 / t == 1 strategy pairs -- and make the
+ * render INVALID; the shipped library refuses them. */
+#define CL2_DEBUG_KNOWN_BITS 0x00FFF7FF
 int cl2_set_debug_flags(cl2_renderer* r, int flags);
+/* Whole-subpath launch (traversal mode 4): lanes that must have gathered with a known closest hit before a wave runs
+ * its bounce phase, and the steps the first of them waits at most.  0 = default (32 lanes, 48 steps).  Same results. */
+int cl2_set_subpath_gather(cl2_renderer* r, int lanes, int wait_steps);
 int cl2_reset_counters(cl2_renderer* r);
 
 /* Exactness self-test: the kernels replace `1.0f/a` and `x/PI` by cheaper sequences that are proven

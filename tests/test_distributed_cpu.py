@@ -146,3 +146,135 @@ def test_unique_id_bootstrap_edge_cases(tmp_path, monkeypatch):
     assert d.rendezvous_path() != a and str(os.getppid()) in a
     monkeypatch.setenv("CLIVE2_RENDEZVOUS_FILE", "/tmp/explicit")
     assert d.rendezvous_path() == "/tmp/explicit"
+
+
+def _build_wait_stub(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "comm_wait_stub")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "comm_wait_stub.cpp"), "-o", exe], check=True)
+    return exe
+
+
+def test_collective_wait_has_a_deadline_and_aborts(tmp_path):
+    """a rank that never joins a collective must not leave its peers blocked for ever.  The
+    library waits for an enqueued collective with wait_collective() (csrc/comm_wait.hpp: stream + async-error
+    polling under a deadline) and aborts the communicator on failure.  Two processes, CPU stand-ins for
+    stream and communicator: rank 1 skips the collective, rank 0 must return an error within its deadline."""
+    import subprocess
+    import time
+    exe = _build_wait_stub(tmp_path)
+    d = tmp_path / "skip"; d.mkdir()
+    t0 = time.monotonic()
+    p0 = subprocess.Popen([exe, str(d), "0", "2", "1", "1.0"], stdout=subprocess.PIPE, text=True)
+    p1 = subprocess.Popen([exe, str(d), "1", "2", "0", "1.0"], stdout=subprocess.PIPE, text=True)
+    out1, _ = p1.communicate(timeout=30)
+    out0, _ = p0.communicate(timeout=30)
+    waited = time.monotonic() - t0
+    assert p1.returncode == 0 and "skipped" in out1
+    assert p0.returncode == 5 and "TIMEOUT" in out0            # -CL2_E_COMM, not a hang
+    assert 0.9 < waited < 10.0
+    assert (d / "aborted.0").exists()                           # the communicator was torn down (ncclCommAbort in the library)
+
+    # positive control: both join (rank 1 late) -> both complete, nobody aborts
+    d = tmp_path / "both"; d.mkdir()
+    p0 = subprocess.Popen([exe, str(d), "0", "2", "1", "20"], stdout=subprocess.PIPE, text=True)
+    time.sleep(0.3)
+    p1 = subprocess.Popen([exe, str(d), "1", "2", "1", "20"], stdout=subprocess.PIPE, text=True)
+    assert p0.wait(timeout=30) == 0 and p1.wait(timeout=30) == 0
+    assert not list(d.glob("aborted.*"))
+
+    # an asynchronous communicator error ends the wait at once, long before the deadline
+    d = tmp_path / "async"; d.mkdir()
+    (d / "async_error").write_text("x")
+    t0 = time.monotonic()
+    p0 = subprocess.run([exe, str(d), "0", "2", "1", "60"], stdout=subprocess.PIPE, text=True, timeout=30)
+    assert p0.returncode == 5 and "ASYNC_ERROR detail 6" in p0.stdout and time.monotonic() - t0 < 5.0
+
+
+def _run_bench(args, env_extra=None, timeout=120):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "CLIVE2_RENDEZVOUS_FILE")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python3 bench.py --gpus N` (the driver's command form) must start N rank processes
+    itself.  `--dry-spawn` makes the ranks stop after the communicator-id hand-over (128 random bytes through the
+    shared rendezvous file), so the whole launch path runs here without a GPU: N children, distinct ranks, one
+    rendezvous path handed to all, the same id everywhere, ONE line on stdout, nothing left behind."""
+    import json
+    import tempfile
+    before = set(os.listdir(tempfile.gettempdir()))
+    p = _run_bench(["--gpus", "4", "--dry-spawn", "--steps", "3", "--warmup", "1"])
+    assert p.returncode == 0, p.stderr
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1                                        # rank 0's line only
+    out = json.loads(lines[0])
+    assert out["dry_spawn"] and out["n_gpus"] == 4 and out["ids_equal"]
+    ranks = out["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1, 2, 3] and [r["local_rank"] for r in ranks] == [0, 1, 2, 3]
+    assert all(r["world"] == 4 for r in ranks)
+    assert len({r["pid"] for r in ranks}) == 4                    # four processes ...
+    assert len({r["ppid"] for r in ranks}) == 1                   # ... of one parent
+    assert len({r["rendezvous"] for r in ranks}) == 1 and ranks[0]["rendezvous"] == ranks[0]["explicit_file"]
+    left = [f for f in set(os.listdir(tempfile.gettempdir())) - before if f.startswith("clive2_bench_id_")]
+    assert not left
+
+
+def test_bench_spawn_propagates_a_rank_failure():
+    """A rank that exits non-zero ends the job: the parent stops the other ranks (which would otherwise wait for
+    the id / in a collective), exits non-zero itself and prints no result line."""
+    import time
+    t0 = time.monotonic()
+    p = _run_bench(["--gpus", "3", "--dry-spawn"], env_extra={"CLIVE2_BENCH_DRY_FAIL_RANK": "0"})
+    assert p.returncode == 3 and p.stdout.strip() == "" and "rank 0 exited with 3" in p.stderr
+    assert time.monotonic() - t0 < 30.0                           # not the ranks' own 60 s id timeout
+    p = _run_bench(["--gpus", "3", "--dry-spawn"], env_extra={"CLIVE2_BENCH_DRY_FAIL_RANK": "2"})
+    assert p.returncode == 3 and p.stdout.strip() == ""
+
+
+def test_bench_single_process_paths_are_unchanged():
+    """--gpus 1 does not spawn; under a launcher environment (WORLD_SIZE set) the script is a rank, whatever --gpus says;
+    the invalid-render debug bits are refused."""
+    import json
+    p = _run_bench(["--gpus", "1", "--dry-spawn"])
+    out = json.loads(p.stdout)
+    assert p.returncode == 0 and out["n_gpus"] == 1 and out["ranks"][0]["explicit_file"] is None
+    p = _run_bench(["--gpus", "8", "--dry-spawn"], env_extra={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert p.returncode == 0 and json.loads(p.stdout)["n_gpus"] == 1
+    p = _run_bench(["--debug-flags", "1"])
+    assert p.returncode != 0 and "invalid renders" in p.stderr
+
+
+def test_rendezvous_file_is_private_and_fresh(tmp_path):
+    """the id file is created exclusively with mode 0600 and read without following symlinks; a file that
+    predates this process (a crashed attempt with the same name) is ignored; the key of the default name changes with
+    the launcher's restart count."""
+    from clive2_amd import distributed as d
+    path = str(tmp_path / "id")
+    uid = d.exchange_unique_id(0, 2, lambda: b"k" * 128, 128, path=path)
+    assert uid == b"k" * 128 and (os.stat(path).st_mode & 0o777) == 0o600
+    assert d.exchange_unique_id(1, 2, None, 128, path=path, timeout=1.0) == uid
+    link = str(tmp_path / "link")
+    os.symlink(path, link)
+    with pytest.raises(TimeoutError):
+        d.exchange_unique_id(1, 2, None, 128, path=link, timeout=0.2)       # symlinks are not followed
+    old = d._T_IMPORT
+    try:
+        d._T_IMPORT = os.path.getmtime(path) + d._STALE_SLACK_S + 5.0      # as if this process had started much later
+        with pytest.raises(TimeoutError):
+            d.exchange_unique_id(1, 2, None, 128, path=path, timeout=0.2)
+    finally:
+        d._T_IMPORT = old
+    env = dict(os.environ)
+    try:
+        for k in ("CLIVE2_RENDEZVOUS_FILE",):
+            os.environ.pop(k, None)
+        os.environ["TORCHELASTIC_RESTART_COUNT"] = "0"
+        a = d.rendezvous_path()
+        os.environ["TORCHELASTIC_RESTART_COUNT"] = "1"
+        assert d.rendezvous_path() != a
+    finally:
+        os.environ.clear(); os.environ.update(env)

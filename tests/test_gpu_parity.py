@@ -162,7 +162,7 @@ def test_levels_per_launch_is_a_pure_performance_knob(levels, glass_scene, oracl
 
 
 @pytest.mark.parametrize("mode", [2, 4, 5])
-@pytest.mark.parametrize("flags", [0, 1 << 12, (4 << 13) | (1 << 16) | (1 << 24), (7 << 13) | (64 << 16) | (100 << 24) | (1 << 12)])
+@pytest.mark.parametrize("flags", [(0, 0, 0), (1 << 12, 0, 0), (4 << 13, 1, 1), ((7 << 13) | (1 << 12), 64, 100)])
 @pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
 def test_persistent_traversal_mode_is_equivalent(scene_name, flags, mode, request, oracle_mod):
     """traversal_mode 2 (persistent launches with lane-level ray replacement + one bounce launch per
@@ -170,11 +170,12 @@ def test_persistent_traversal_mode_is_equivalent(scene_name, flags, mode, reques
     wave: the large-scene organisation) reproduce the oracle exactly, like the fused mode -- in
     both forms of the step (two triangles per step for cache-resident trees, bit 12 selects the
     one-triangle form used for trees that stream from memory), and for any register budget (bits 13-15)
-    and bounce batching (bits 16-22: lanes gathered, bits 24-30: steps waited) of the whole-subpath launch."""
+    and bounce batching (cl2_set_subpath_gather: lanes gathered, steps waited) of the whole-subpath launch."""
     scene = request.getfixturevalue(scene_name)
     r, o = _pair(scene, oracle_mod)
     r.set_traversal_mode(mode)
-    r.set_debug_flags(flags)
+    r.set_debug_flags(flags[0])
+    r.set_subpath_gather(flags[1], flags[2])
     _run_to_paths(r, o)
     for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
         assert r.export_paths(which).tobytes() == ref.tobytes()

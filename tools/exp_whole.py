@@ -8,9 +8,9 @@ import bench
 from clive2_amd.renderer import Renderer, make_seeds
 
 
-def run(scene, W, H, mode, flags, pipelining, n=24):
+def run(scene, W, H, mode, flags, pipelining, n=24, gather=(0, 0)):
     r = Renderer(scene, seeds=make_seeds(W * H))
-    r.set_traversal_mode(mode); r.set_debug_flags(flags); r.set_pipelining(pipelining)
+    r.set_traversal_mode(mode); r.set_debug_flags(flags); r.set_subpath_gather(*gather); r.set_pipelining(pipelining)
     r.run_samples(4)
     r.reset_counters()
     t0 = time.perf_counter()
@@ -33,10 +33,10 @@ def main():
     print(f"mode 2 pipelined         {ms:8.3f} ms  {gr:6.3f} Grays/s", flush=True)
     for wps in (4, 5, 6, 7):
         for lanes, wait in ((8, 16), (16, 24), (24, 32), (32, 48), (48, 64)):
-            flags = (wps << 13) | (lanes << 16) | (wait << 24)
-            ms, gr, u = run(scene, W, H, 4, flags, 0)
+            flags = wps << 13
+            ms, gr, u = run(scene, W, H, 4, flags, 0, gather=(lanes, wait))
             same = u.tobytes() == ref.tobytes()
-            ms1, gr1, _ = run(scene, W, H, 4, flags, 1)
+            ms1, gr1, _ = run(scene, W, H, 4, flags, 1, gather=(lanes, wait))
             print(f"mode 4 wps {wps if wps < 7 else 8} lanes {lanes:2d} wait {wait:2d}: serial {ms:8.3f} ms {gr:6.3f} Grays/s | pipelined {ms1:8.3f} ms {gr1:6.3f} Grays/s"
                   f"  {'same' if same else 'DIFFERENT'}", flush=True)
 

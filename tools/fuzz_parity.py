@@ -62,8 +62,9 @@ def main():
         mode, levels, stages = int(rng.randint(0, 6)), int(rng.randint(0, 7)), int(rng.randint(-1, 3))
         r.set_traversal_mode(mode)
         if rng.rand() < 0.5:                # whole-subpath launch: random register budget and bounce batching, either step form
-            r.set_debug_flags((int(rng.choice([0, 4, 5, 6, 7])) << 13) | (int(rng.randint(0, 65)) << 16) |
-                              (int(rng.randint(0, 100)) << 24) | (int(rng.randint(0, 2)) << 12))
+            budget, lanes, wait, step = int(rng.choice([0, 4, 5, 6, 7])), int(rng.randint(0, 65)), int(rng.randint(0, 100)), int(rng.randint(0, 2))
+            r.set_debug_flags((budget << 13) | (step << 12))
+            r.set_subpath_gather(lanes, wait)
         r.set_levels_per_launch(levels)
         r.set_pipelining(stages)
         t0 = time.time()
