@@ -47,7 +47,8 @@ struct WideView {
     const float4* nodes;       // 8 float4 per wide node
     const float4* tris;        // 3 float4 per triangle (the binary walk's array)
     float4 root_lo, root_hi;   // the root box: tested once per ray, as the reference does
-    int2* overflow;            // [lanes of the launch][WIDE_STACK_OVERFLOW]
+    int2* overflow;            // [lanes of the launch][ovf_stride]
+    int ovf_stride;            // entries per lane: the deepest stack the uploaded tree can produce (<= WIDE_STACK_OVERFLOW)
     int stack_lds;             // stack entries kept in LDS per lane (<= WIDE_STACK_LDS)
     int n_lds_nodes;           // wide nodes [0, n_lds_nodes) (breadth-first numbering: the top of the tree) staged in LDS
 };
@@ -63,7 +64,7 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
     float* s_tmin = reinterpret_cast<float*>(s_ref) + S * nt;
     for (int i = tid; i < 8 * w.n_lds_nodes; i += nt) s_nodes[i] = w.nodes[i];
     __syncthreads();
-    int2* ovf = w.overflow + ((size_t)blockIdx.x * nt + tid) * WIDE_STACK_OVERFLOW;
+    int2* ovf = w.overflow + ((size_t)blockIdx.x * nt + tid) * w.ovf_stride;
     const int lane = tid & 63;
     const unsigned waves = gridDim.x * (blockDim.x >> 6);
     unsigned chunk = n / (waves * 4u);

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
         for (int i = tid; i < 8 * wide.n_lds_nodes; i += BLOCK) s_wnodes[i] = wide.nodes[i];
         __syncthreads();
         b.n_lds_nodes = 0; b.lds_tris = 0; b.n_fast_nodes = 0;   // the binary records (rays with a non-finite 1/d) come through the caches
-        ovf = wide.overflow + ((size_t)blockIdx.x * BLOCK + tid) * WIDE_STACK_OVERFLOW;
+        ovf = wide.overflow + ((size_t)blockIdx.x * BLOCK + tid) * wide.ovf_stride;
     } else {
         stage_bvh(s, bvh);                                 // ends with the barrier
     }

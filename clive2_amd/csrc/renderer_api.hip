@@ -77,7 +77,8 @@ struct cl2_renderer {
     int n_fast = 0;                      // records of the pruned table (bvh.n_fast_nodes unless debug_flags bit 7 switches it off)
     float4* d_fast = nullptr;            // pruned record table of an LDS-resident tree (cl2_upload_scene); bvh.n_fast_nodes == 0: none
     WideView wide{};
-    int2* d_wide_ovf = nullptr;          // per-lane stack overflow of the wide launches (one region per stage: [2])
+    int2* d_wide_ovf = nullptr;          // per-lane stack overflow of the wide launches (one region per stage: [2]); allocated by the first wide launch
+    int wide_ovf_entries = 0;            // entries per lane: the deepest stack this tree can produce (cl2_upload_scene)
     CameraRec cam{};
 
     // state
@@ -304,11 +305,24 @@ inline int persistent_grid_conn(const cl2_renderer* r) {
 
 // One persistent launch of the exact 4-wide walk.  `stage` 0 = subpath stage, 1 = connection stage: each has its own
 // stack-overflow region, since the two run side by side in the sample pipeline.
+// The per-lane stack of a wide walk keeps its first entries in LDS and the rest in a global array.  How deep it can get
+// is a static property of the tree: every entry pending on the reference's stack (at most `pending` of them, counted at
+// upload) stands for at most two wide-stack entries, plus the four a visit pushes.  The array is sized for that bound
+// (not for the 2 x 64 + 8 any admissible tree could reach) and exists only once a wide launch has been asked for:
+// an LDS-resident scene never takes the wide walk on its own, and a turntable builds one renderer per frame.
+int ensure_wide_overflow(cl2_renderer* r) {
+    if (r->d_wide_ovf) return CL2_OK;
+    const size_t lanes = (size_t)persistent_grid() * BLOCK;
+    return dev_alloc(r, &r->d_wide_ovf, 2 * lanes * (size_t)std::max(r->wide_ovf_entries, 1));
+}
+
 template <class Source>
 int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* count, unsigned* work_counter, Source src, int is_conn) {
     const int grid = stage == 0 ? persistent_grid_paths(r) : persistent_grid_conn(r);
+    TRY(ensure_wide_overflow(r));
     WideView w = r->wide;
-    w.overflow = r->d_wide_ovf + (size_t)stage * persistent_grid() * BLOCK * WIDE_STACK_OVERFLOW;
+    w.ovf_stride = std::max(r->wide_ovf_entries, 1);
+    w.overflow = r->d_wide_ovf + (size_t)stage * persistent_grid() * BLOCK * w.ovf_stride;
     // LDS per workgroup: per-lane stack (8 B per entry and lane) + the top of the tree (128 B per wide node); experiment
     // switches: debug_flags bits 16-19 stack entries (0 = default), bits 20-23 window in units of 32 wide nodes
     const int sflag = (r->debug_flags >> 16) & 0xF, wflag = (r->debug_flags >> 20) & 0xF;
@@ -395,7 +409,9 @@ int launch_subpaths(cl2_renderer* r, hipStream_t st, const PathBufs* set, int ki
     WideView w = r->wide;
     w.stack_lds = 4; w.n_lds_nodes = 0;
     if (widew) {
+        TRY(ensure_wide_overflow(r));
         w.n_lds_nodes = std::min(r->n_wide, 64);
+        w.ovf_stride = std::max(r->wide_ovf_entries, 1);
         w.overflow = r->d_wide_ovf;                            // stage 0 region: the subpath stage
     }
     const size_t lds = widew ? (size_t)w.stack_lds * BLOCK * 8 + (size_t)w.n_lds_nodes * 128 : bvh_lds_bytes(r);
@@ -871,6 +887,12 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
         }
         std::vector<int> fast_index((size_t)n_records + 1);
         for (int k = 0; k <= n_records; k++) { fast_index[k] = n_fast; if (k < n_records && !dropped[k]) n_fast++; }
+        // LDS budget: the pruned table sits beside the full one (rays with a non-finite 1/d need that) in every workgroup
+        // that stages the tree.  Three such workgroups per CU (160 KB) is what the subpath kernel runs at with its 9.7 KB
+        // of static shading tables; a scene near the 512-record / 512-triangle caps would lose a workgroup per CU to the
+        // extra table (and a 64-KB-per-workgroup part would refuse the launch), so there it is not built.
+        const size_t lds_with_fast = ((size_t)2 * n_records + (size_t)3 * n_tris + (size_t)2 * n_fast) * sizeof(float4) + sizeof(ShadeLds);
+        if (n_fast < n_records && lds_with_fast > (size_t)160 * 1024 / 3) n_fast = n_records;       // -> no table
         if (n_fast < n_records) {
             h_fast.resize(2 * (size_t)n_fast);
             for (int i = 0; i < n_boxes; i++) {
@@ -939,8 +961,11 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     if (n_wide > 0) {
         TRY(dev_alloc(r, &r->d_wide, h_wide.size()));
         HIP_TRY(r, hipMemcpy(r->d_wide, h_wide.data(), h_wide.size() * sizeof(float4), hipMemcpyHostToDevice));
-        const size_t lanes = (size_t)persistent_grid() * BLOCK;
-        if (!r->d_wide_ovf) TRY(dev_alloc(r, &r->d_wide_ovf, 2 * lanes * WIDE_STACK_OVERFLOW));
+        // deepest wide stack of THIS tree (see ensure_wide_overflow); a new scene may need a different size
+        int max_pending = 0;
+        for (int i = 0; i < n_boxes; i++) max_pending = std::max(max_pending, pending[i]);
+        const int entries = std::min((int)WIDE_STACK_OVERFLOW, 2 * max_pending + 4);
+        if (entries != r->wide_ovf_entries) { dev_free(r, r->d_wide_ovf); r->wide_ovf_entries = entries; }
         r->wide.nodes = r->d_wide; r->wide.tris = r->d_tris;
         r->wide.root_lo = make_float4(boxes[0].min[0], boxes[0].min[1], boxes[0].min[2], 0.0f);
         r->wide.root_hi = make_float4(boxes[0].max[0], boxes[0].max[1], boxes[0].max[2], 0.0f);

@@ -593,6 +593,16 @@ static void world_ray_to_camera_ray(const Box *boxes, const Triangle *triangles,
     camera_ray->hit_camera = best_i;
 }
 
+/* Strategy log (tests only): when set, connect_paths_one records for every CONNECTED pair (t,s) of every pixel what the
+ * MIS stage computed -- record (id*7 + t)*7 + s of STRATEGY_LOG_STRIDE floats:
+ *   [0] 1.0 (pair produced a weight)  [1] w  [2] p_s  [3] sum of p_values  [4] g  [5..7] color  [8] s+t
+ *   [9..9+13) p_values[0..12] after the specular zeroing and p_values[s+t] = 0 (trace.metal:745-771).
+ * The log has no influence on any result. */
+#define STRATEGY_LOG_STRIDE 24
+static float *g_strategy_log = NULL;
+void orc_set_strategy_log(float *buf) { g_strategy_log = buf; }
+int orc_strategy_log_stride(void) { return STRATEGY_LOG_STRIDE; }
+
 /* ---- K5 connect_paths, trace.metal:620-869 ---- */
 static void connect_paths_one(uint32_t id, const Path *camera_paths, const Path *light_paths,
                               const Triangle *triangles, const Material *materials, const Box *boxes,
@@ -736,6 +746,12 @@ static void connect_paths_one(uint32_t id, const Path *camera_paths, const Path 
                 }
                 color = vmul(camera_color, light_color);
                 g = cosine_geometry_term(&camera_ray, &light_ray);
+            }
+            if (g_strategy_log) {
+                float *rec = g_strategy_log + ((size_t)(id * 7u + (uint32_t)t) * 7u + (uint32_t)s) * STRATEGY_LOG_STRIDE;
+                rec[0] = 1.0f; rec[1] = w; rec[2] = p_s; rec[3] = sum; rec[4] = g;
+                rec[5] = color.x; rec[6] = color.y; rec[7] = color.z; rec[8] = (float)(s + t);
+                for (int i = 0; i < 13; i++) rec[9 + i] = p_values[i];
             }
             if (t != 1) {
                 aggregator.total_contribution = vadd(aggregator.total_contribution, vdivs(vscale(color, w * g), p_s));

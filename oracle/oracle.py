@@ -98,6 +98,34 @@ def traverse(rays, boxes, triangles):
     return bi, bt, u, v, cnt[0]
 
 
+def strategy_log(renderer):
+    """Runs `renderer.join_paths()` with the strategy log on: returns a float32 array [B, 7, 7, 24], record [id, t, s] =
+    {1.0 if the pair produced a weight, w, p_s, sum(p_values), g, color.xyz, s+t, p_values[0..12], pad} (bdpt_oracle.c:
+    orc_set_strategy_log).  Tests only."""
+    L = renderer.L
+    stride = L.orc_strategy_log_stride()
+    buf = np.zeros((renderer.batch_size, 7, 7, stride), np.float32)
+    L.orc_set_strategy_log(_p(buf))
+    try:
+        renderer.join_paths()
+    finally:
+        L.orc_set_strategy_log(None)
+    return buf
+
+
+def stage_hashes(renderer):
+    """SHA-256 of what one full sample leaves behind on a renderer (oracle or product: both expose the same arrays through
+    the same names): both Path[] buffers, the filter aggregators, the RNG buffer.  The drift pin of tests/golden/."""
+    import hashlib
+    def h(a):
+        return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    return {"light_paths": h(renderer.out_light_paths), "camera_paths": h(renderer.out_camera_paths),
+            "aggregator_total": h(renderer.weight_aggregators["total_contribution"]),
+            "aggregator_weights": h(renderer.weight_aggregators["weights"]),
+            "aggregator_weight_sum": h(renderer.weight_aggregators["contrib_weight_sum"]),
+            "seeds": h(renderer.rand_buffer)}
+
+
 def make_seeds(batch, seed=20240928, rank=0):
     """Seed buffer of SURVEY.md §8(d): same call shape as renderer.py:86-87, but seeded, and with
     zeros (the xorshift fixed point) replaced by 1."""

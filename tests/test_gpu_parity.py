@@ -572,6 +572,35 @@ def test_pruned_table_is_equivalent(scene_name, mode, request, oracle_mod):
     r.close(); full.close()
 
 
+def test_scene_near_the_lds_caps_keeps_its_residency(oracle_mod):
+    """the pruned table shares the workgroup's LDS with the full record table, the staged triangles and the
+    subpath kernel's 9.7 KB of shading tables.  Near the 512-record / 512-triangle caps it is left out when it would
+    take the kernels below three workgroups per CU (160 KB / 3); the launch succeeds either way and stays bit-exact."""
+    import clive2_amd as c2
+    from clive2_amd.load import get_materials
+    from clive2_amd.meshes import icosphere
+    mats = get_materials()
+    mats["alpha"][5] = 0.1
+    specs = [dict(mesh=icosphere(2, radius=1.6, center=(0.0, 0.5, 0.0)), material=5),
+             dict(mesh=icosphere(1, radius=1.0, center=(-4.0, 0.0, -3.0)), material=3),
+             dict(mesh=icosphere(1, radius=1.0, center=(4.0, 0.0, -3.0)), material=1)]
+    scene = c2.create_scene(64, 48, np.array([0, 1.5, 6]), np.array([0, 0, -1]), file_specs=specs, materials=mats)
+    assert 480 <= len(scene.triangles) <= 512
+    r, o = _pair(scene, oracle_mod)
+    org = r.organisation()
+    assert org["tree_in_lds"] == 1
+    lds = (2 * org["n_records"] + 3 * len(scene.triangles) + 2 * org["pruned_records"]) * 16 + 9728
+    assert lds <= 160 * 1024 // 3 or org["pruned_records"] == 0, (org, lds)
+    _run_to_paths(r, o)
+    for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
+        assert r.export_paths(which).tobytes() == ref.tobytes()
+    _run_rest(r, o)
+    assert r.export_aggregators()["total_contribution"].tobytes() == o.weight_aggregators["total_contribution"].tobytes()
+    r.run_samples(4)
+    assert np.isfinite(r.read_accumulators()[0]).all()
+    r.close()
+
+
 @pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
 def test_wide_resolve_kernel_agrees(scene_name, request, oracle_mod):
     """The second implementation of the resolve stage (one wave per camera vertex, running total relayed
