@@ -9,6 +9,7 @@ from clive2_amd.renderer import Renderer, make_seeds
 def run(scene, W, H, mode, flags, pipelining, n):
     r = Renderer(scene, seeds=make_seeds(W * H))
     r.set_traversal_mode(mode); r.set_debug_flags(flags); r.set_pipelining(pipelining)
+    r.tune()
     r.run_samples(4)
     r.reset_counters()
     if pipelining == 0:
@@ -37,7 +38,7 @@ def main():
         ms, gr, uni, org = run(scene, W, H, mode, flags, pipe, n)
         ref = uni if ref is None else ref
         print(f"mode {mode} flags {flags:#x} pipe {pipe}: {ms:8.3f} ms {gr:6.3f} Grays/s  {'same' if uni.tobytes() == ref.tobytes() else 'DIFFERENT'}  "
-              f"window {org['n_lds_records']} share {org['paths_share']} {run.last}", flush=True)
+              f"window {org['n_lds_records']} share {org['paths_share']} wide {org['wide_connections']} {run.last}", flush=True)
 
 
 if __name__ == "__main__":
