@@ -117,7 +117,7 @@ def static_pmc(scene, W, H):
     return None
 
 
-def build_scene(name, W, H):
+def build_scene(name, W, H, builder=None):
     import numpy as np
     import clive2_amd as c2
     if name == "cornell":
@@ -141,7 +141,8 @@ def build_scene(name, W, H):
     else:
         specs = [dict(mesh=(v, f), material=m) for v, f, m in meshes.interior_grid()]
         desc = "Cornell box + 49 x 20,480-tri icospheres (config 5 stand-in)"
-    s = c2.create_scene(W, H, np.array([0, 1.5, 6]), np.array([0, 0, -1]), file_specs=specs, materials=mats, room=room)
+    s = c2.create_scene(W, H, np.array([0, 1.5, 6]), np.array([0, 0, -1]), file_specs=specs, materials=mats, room=room,
+                        bvh_builder=builder or os.environ.get("CLIVE2_BENCH_BVH_BUILDER", "auto"))
     return s, desc + f", {len(s.triangles)} tris / {len(s.boxes)} boxes"
 
 

@@ -169,7 +169,7 @@ class _FlatTree:
 
 def _construct_native(root_box, gpu=False, device=0):
     """C++ builders of libclive2_amd.so: the host SAH builder (the reference's rule, O(n log n)) or, with `gpu`,
-    the LBVH builder on the GPU (another valid tree in the same convention, built in milliseconds)."""
+    the PLOC builder on the GPU (another valid tree in the same convention, built in milliseconds)."""
     import ctypes as C
     from . import _native
     L = _native.lib()
@@ -202,7 +202,7 @@ def construct_BVH(root_box, builder="auto"):
 
     builder: "numpy" = this module's restatement (identical to the reference's tree, ties
     included); "native" = the C++ builder in libclive2_amd.so (same rule, O(n log n), equal
-    centroids ordered by id); "auto" = native above NATIVE_THRESHOLD triangles; "gpu" = the LBVH builder on the
+    centroids ordered by id); "auto" = native above NATIVE_THRESHOLD triangles; "gpu" = the PLOC builder on the
     GPU (csrc/bvh_builder_gpu.hip): a different valid tree, for when set-up time matters (needs a GPU)."""
     if builder == "gpu":
         return _construct_native(root_box, gpu=True)

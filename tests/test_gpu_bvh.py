@@ -1,4 +1,5 @@
-"""GPU BVH builder (csrc/bvh_builder_gpu.hip): an LBVH emitted in the reference's flattened
+"""GPU BVH builder (csrc/bvh_builder_gpu.hip): a PLOC tree (round 3; the round-2 LBVH behind
+CLIVE2_GPU_BVH=lbvh) emitted in the reference's flattened
 Box[] / Triangle[] convention (np_flatten_bvh, src/bvh.py:329-389).  The tree differs from the reference's SAH tree,
 so parity is checked the way the tracer is: render on the GPU-built tree and compare with the oracle (the reference's
 stack walk, trace.metal:144-176) run on the SAME Box[]."""
@@ -150,8 +151,8 @@ def test_gpu_builder_on_the_million_triangle_scene(oracle_mod):
         t0 = time.perf_counter()
         assert L.cl2_build_bvh_gpu(0, _native.ptr(lo), _native.ptr(hi), n, 8, _native.ptr(boxes), len(boxes), C.byref(nb), _native.ptr(perm)) == 0
         best = min(best, time.perf_counter() - t0)
-    print(f"\nGPU LBVH of {n} triangles: {best * 1e3:.0f} ms, {nb.value} boxes, deepest pending {deepest}; create_scene {t_scene:.2f} s")
-    assert best < 1.0
+    print(f"\nGPU PLOC build of {n} triangles: {best * 1e3:.0f} ms, {nb.value} boxes, deepest pending {deepest}; create_scene {t_scene:.2f} s")
+    assert best < 0.25                       # 53 ms measured ("build call still < 0.1 s"); slack for a busy box
     seeds = make_seeds(96 * 54)
     r, o = Renderer(scene, seeds=seeds), oracle_mod.OracleRenderer(scene, seeds=seeds)
     for x in (r, o):
@@ -163,3 +164,45 @@ def test_gpu_builder_on_the_million_triangle_scene(oracle_mod):
     assert r.export_aggregators()["total_contribution"].tobytes() == o.weight_aggregators["total_contribution"].tobytes()
     assert r.counters()["rays"] == o.rays_traced
     np.testing.assert_allclose(r.read_accumulators()[0], o.summed_image, rtol=5e-5, atol=1e-8)
+
+
+def test_ploc_tree_costs_fewer_tests_than_the_radix_tree(monkeypatch):
+    """the quality of the GPU-built tree.  Same scene, same rays (same seeds): the PLOC tree needs fewer node
+    tests AND fewer triangle tests per ray than the round-2 LBVH (1080p: 68.1 + 18.0 against 75.5 + 24.0; the host SAH tree:
+    57.9 + 23.0 -- and renders a sample in the same time as the SAH tree, 31.4 ms, where the LBVH took 35.0)."""
+    from clive2_amd import meshes
+    from clive2_amd.renderer import Renderer, make_seeds
+    specs = [dict(mesh=(v, f), material=m) for v, f, m in meshes.interior_grid()]
+    tests = {}
+    for method in ("lbvh", "ploc"):
+        monkeypatch.setenv("CLIVE2_GPU_BVH", method)
+        scene = _scene(specs, 96, 54, "gpu")
+        _check_convention(scene)
+        r = Renderer(scene, seeds=make_seeds(96 * 54))
+        r.set_counting(True)
+        r.run_samples(2)
+        c = r.counters()
+        tests[method] = (c["box_tests"] / c["counted_rays"], c["tri_tests"] / c["counted_rays"], len(scene.boxes))
+        r.close()
+    print("\nnode / triangle tests per ray, boxes:", tests)
+    assert tests["ploc"][0] < 0.95 * tests["lbvh"][0] and tests["ploc"][1] < 0.9 * tests["lbvh"][1]
+    assert tests["ploc"][2] != tests["lbvh"][2]          # two different trees were really built
+
+
+def test_ploc_builder_survives_coincident_triangles():
+    """Every round of PLOC merges at least the pair with the smallest (area, position, position) key; a soup of identical
+    boxes merges ONE pair per round, so past a cap of rounds the builder falls back to the radix tree.  Either way the
+    result is a valid tree."""
+    import ctypes as C
+    from clive2_amd import _native, struct_types as st
+    L = _native.lib()
+    L.cl2_build_bvh_gpu.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                    C.POINTER(C.c_int64), C.c_void_p]
+    for n in (40, 3000):                                  # below / above the cap of rounds
+        lo = np.tile(np.array([[0.25, 0.5, 0.75]]), (n, 1)); hi = lo + 0.5
+        boxes, perm, nb = np.zeros(2 * n, st.Box), np.full(n, -1, np.int64), C.c_int64(0)
+        assert L.cl2_build_bvh_gpu(0, _native.ptr(lo), _native.ptr(hi), n, 8, _native.ptr(boxes), len(boxes), C.byref(nb), _native.ptr(perm)) == 0
+        assert np.array_equal(np.sort(perm), np.arange(n))
+        b = boxes[:nb.value]
+        leaves = b[b["right"] != 0]
+        assert (leaves["right"] - leaves["left"]).sum() == n and (leaves["right"] - leaves["left"]).max() <= 8
