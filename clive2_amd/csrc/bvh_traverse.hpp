@@ -189,6 +189,14 @@ __device__ __forceinline__ void tri_test(V3 o, V3 d, float4 a0, float4 a1, float
 }
 
 constexpr int RAY_CHUNK_MAX = 512;  // rays handed to a wave per global atomic: 64..512, about a quarter of a wave's fair share
+// Lanes whose ray is finished take a new one only when at least REFILL_MIN of them are idle (or nobody is walking).  The
+// refill is all-wave code for a handful of lanes -- a tag load, two dependent vertex gathers, a normalisation and three
+// exact reciprocals, and the wave waits for those loads before its next node fetch -- so running it in EVERY pass for the
+// one or two lanes that just finished puts two extra memory round trips on every pass's critical path.  Same-box A/B
+// (tools/exp_ab_scene.py, connection launch alone, ms): 1M triangles, binary walk 15.7 -> 14.5 / 14.0 / 14.0 / 15.8 at
+// 16 / 24 / 32 / 48 lanes; glass, 4-wide walk 3.90 -> 3.81 / 3.86 / 3.80 / 4.14; blob 5.12 -> 5.03 / 5.04 / 5.10 / 6.10.
+constexpr int REFILL_MIN_BINARY = 24;
+constexpr int REFILL_MIN_WIDE = 16;
 
 template <bool COUNT, bool TWO_TRIS, class Source>
 __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhView& b, unsigned n, unsigned* work_counter,
@@ -212,6 +220,7 @@ __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhVi
     while (true) {
         // ---- refill idle lanes ----
         unsigned long long idle = __ballot(!active);
+        if (__popcll(idle) < REFILL_MIN_BINARY && __popcll(idle) < 64) idle = 0;               // not yet: see REFILL_MIN_BINARY
         while (idle && !dry) {
             if (w_next >= w_end) {             // wave-uniform branch: fetch a new chunk
                 unsigned base = 0;

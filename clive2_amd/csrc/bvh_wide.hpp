@@ -103,6 +103,7 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
     while (true) {
         // ---- refill idle lanes ----
         unsigned long long idle = __ballot(!active);
+        if (__popcll(idle) < REFILL_MIN_WIDE && __popcll(idle) < 64) idle = 0;                 // not yet: see REFILL_MIN_WIDE (bvh_traverse.hpp)
         while (idle && !dry) {
             if (w_next >= w_end) {
                 unsigned base = 0;
