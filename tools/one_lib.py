@@ -1,0 +1,13 @@
+"""One library, one scene, a few serial samples (for rocprofv3 passes of A/B builds):  python3 tools/one_lib.py <lib.so> <scene> [samples]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import clive2_amd._native as n
+n.LIB_PATH = os.path.abspath(sys.argv[1])
+import bench
+from clive2_amd.renderer import Renderer, make_seeds
+scene, desc = bench.build_scene(sys.argv[2], 1920, 1080)
+r = Renderer(scene, seeds=make_seeds(1920 * 1080))
+r.set_pipelining(0)
+r.run_samples(int(sys.argv[3]) if len(sys.argv) > 3 else 3)
+r.synchronize()
+print("done", r.counters()["rays"])
