@@ -215,7 +215,7 @@ __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhVi
     Hit best{-1, __builtin_inff(), 0.0f, 0.0f};
     const int n_nodes = b.n_nodes;
     int node = n_nodes, tri_i = 0, tri_end = 0;
-    unsigned key = 0;
+    int key = 0;                               // the source's token of the lane's ray (pixel id / tag): store() needs it again
 
     while (true) {
         // ---- refill idle lanes ----
@@ -234,8 +234,7 @@ __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhVi
             const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
             const bool take = !active && rank < avail;
             if (take) {
-                key = w_next + rank;
-                src.load(key, o, d);
+                key = src.load(w_next + rank, o, d);
                 inv = rcp3(d);
                 fast = finite3(inv);
                 best = Hit{-1, __builtin_inff(), 0.0f, 0.0f};

@@ -79,7 +79,7 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
     int node = 0x7fffffff;                     // binary walk of a ray with a non-finite 1/d (wlane == false)
     bool wlane = true;
     const int n_nodes = b.n_nodes;
-    unsigned key = 0;
+    int key = 0;                               // the source's token of the lane's ray (pixel id / tag): store() needs it again
 
     auto push = [&](int ref, float tmin) {
         if (sp < S) { s_ref[sp * nt + tid] = ref; s_tmin[sp * nt + tid] = tmin; }
@@ -116,8 +116,7 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
             const unsigned avail = w_end - w_next;
             const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
             if (!active && rank < avail) {
-                key = w_next + rank;
-                src.load(key, o, d);
+                key = src.load(w_next + rank, o, d);
                 inv = rcp3(d);
                 best = Hit{-1, __builtin_inff(), 0.0f, 0.0f};
                 cur = -1; tri_i = 0; tri_end = 0; sp = 0;

@@ -213,12 +213,17 @@ __global__ __launch_bounds__(BLOCK) void k_traverse_paths(
 }
 
 // ---------------------------------------------------------------- persistent traversal kernels (large scenes)
+// Ray sources of the persistent walks: load(j) fetches ray j of the launch and returns the TOKEN the lane keeps while it
+// walks (pixel id / connection tag), store(token, hit) writes the result -- without going back to the queue for it.
 struct PathRaySource {          // subpath rays: queue entry -> pixel -> (P0.xyz, P1.xyz) of one level
     const int* queue; const float4* P0v; const float4* P1v; float4* hit;
-    __device__ __forceinline__ int pid(unsigned j) const { return queue ? queue[j] : (int)j; }
-    __device__ __forceinline__ void load(unsigned j, V3& o, V3& d) const { const int p = pid(j); o = v3(P0v[p]); d = v3(P1v[p]); }
-    __device__ __forceinline__ void store(unsigned j, const Hit& h) const {
-        hit[pid(j)] = make_float4(__int_as_float(h.tri), h.t, h.u, h.v);
+    __device__ __forceinline__ int load(unsigned j, V3& o, V3& d) const {
+        const int p = queue ? queue[j] : (int)j;
+        o = v3(P0v[p]); d = v3(P1v[p]);
+        return p;
+    }
+    __device__ __forceinline__ void store(int pid, const Hit& h) const {
+        hit[pid] = make_float4(__int_as_float(h.tri), h.t, h.u, h.v);
     }
 };
 
@@ -238,7 +243,7 @@ __device__ __forceinline__ float2 chit_load(const float2* chit, int B, int t, in
 
 struct ConnRaySource {          // connection rays: tag {slot, pixel} -> light vertex s-1 toward focal point / camera vertex t-1
     const int* ctag; const float4* LP0; const float4* CP0; float2* chit; V3 focal; int B;
-    __device__ __forceinline__ void load(unsigned j, V3& o, V3& d) const {
+    __device__ __forceinline__ int load(unsigned j, V3& o, V3& d) const {
         const int tag = ctag[j];
         const int pid = tag & ((1 << TAG_PID_BITS) - 1), slot = (unsigned)tag >> TAG_PID_BITS;
         const int t = slot / 6 + 1, s = slot % 6 + 1;
@@ -246,9 +251,9 @@ struct ConnRaySource {          // connection rays: tag {slot, pixel} -> light v
         V3 target = focal;
         if (t > 1) target = v3(CP0[(size_t)(t - 1) * B + pid]);
         d = normalize(target - o);
+        return tag;
     }
-    __device__ __forceinline__ void store(unsigned j, const Hit& h) const {
-        const int tag = ctag[j];
+    __device__ __forceinline__ void store(int tag, const Hit& h) const {
         const int pid = tag & ((1 << TAG_PID_BITS) - 1), slot = (unsigned)tag >> TAG_PID_BITS;
         chit_store(chit, B, slot, pid, h.tri, h.t);
     }
