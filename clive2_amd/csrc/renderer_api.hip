@@ -415,23 +415,17 @@ int launch_subpaths(cl2_renderer* r, hipStream_t st, const PathBufs* set, int ki
         w.overflow = r->d_wide_ovf;                            // stage 0 region: the subpath stage
     }
     const size_t lds = widew ? (size_t)w.stack_lds * BLOCK * 8 + (size_t)w.n_lds_nodes * 128 : bvh_lds_bytes(r);
-#define CL2_WHOLE(CNT, TWO, WPS, WIDE)                                                                                    \
+    // register budget: 5 waves per SIMD (102 VGPRs: the bounce code; 6 waves cost 64 bytes of scratch per lane and measured
+    // 13.0 -> 13.6 ms on the glass scene, 8 waves 24.5 ms); the grid holds as many workgroups as stay resident
+    constexpr int WPS = 5;
+    const int grid = std::max(1, persistent_grid_paths(r) * WPS / 8);
+#define CL2_WHOLE(CNT, TWO, WIDE)                                                                                         \
     hipLaunchKernelGGL((k_subpaths_persistent<CNT, TWO, WPS, WIDE>), dim3(grid), dim3(BLOCK), lds, st, r->bvh, w,          \
                        r->B, r->d_work, set[CL2_LIGHT], set[CL2_CAMERA], r->d_seeds, r->d_tri_shade, r->d_mats, r->n_mats, \
                        r->d_stats, lanes, wait, kinds)
-    // experiment switch (debug_flags bits 13-15): register budget of the launch as waves per SIMD (4, 5, 6; 7 = 8 waves), 0 = default
-    const int wps_flag = (r->debug_flags >> 13) & 7;
-    const int wps = wps_flag == 7 ? 8 : (wps_flag ? wps_flag : 5);
-    // the grid holds as many workgroups as stay resident (4 waves each): wps per CU-quarter
-    const int grid = std::max(1, persistent_grid_paths(r) * std::min(wps, 8) / 8);
-#define CL2_WHOLE_W(WPS)                                                                                                 \
-    do {                                                                                                                 \
-        if (widew) CL2_WHOLE(false, true, WPS, true);                                                                     \
-        else if (two_tris_per_step(r)) { if (r->counting) CL2_WHOLE(true, true, WPS, false); else CL2_WHOLE(false, true, WPS, false); } \
-        else { if (r->counting) CL2_WHOLE(true, false, WPS, false); else CL2_WHOLE(false, false, WPS, false); }            \
-    } while (0)
-    if (wps <= 4) CL2_WHOLE_W(4); else if (wps == 5) CL2_WHOLE_W(5); else if (wps == 6) CL2_WHOLE_W(6); else CL2_WHOLE_W(8);
-#undef CL2_WHOLE_W
+    if (widew) CL2_WHOLE(false, true, true);
+    else if (two_tris_per_step(r)) { if (r->counting) CL2_WHOLE(true, true, false); else CL2_WHOLE(false, true, false); }
+    else { if (r->counting) CL2_WHOLE(true, false, false); else CL2_WHOLE(false, false, false); }
 #undef CL2_WHOLE
     r->launches_tp++;
     HIP_TRY(r, hipGetLastError());
@@ -491,10 +485,11 @@ int launch_resolve(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
 #define CL2_RESOLVE(W)                                                                                                       \
         hipLaunchKernelGGL(k_connect_resolve<W>, dim3(grid_for(B)), dim3(BLOCK), 0, st, B, lp, cp, r->d_mats, r->d_tri_shade,   \
                            r->cam, r->d_cmask[cs], r->d_chit[cs], r->d_agg, r->d_light_image, r->d_uni, r->d_stats, r->debug_flags)
-        // experiment switch: 0 (default) / 2 / 4 = one thread per pixel at 3 / 2 / 4 waves per SIMD; 7 = one wave per
-        // camera vertex (connect_resolve_wide.hpp: same results bit for bit, measured slower: 1.14 vs 0.93 ms; a second
-        // implementation kept as a cross-check, built only with -DCL2_TEST_VARIANT = libclive2_amd_test.so)
+        // 3 waves per SIMD: what 165 VGPRs and 52 KB of LDS tables per workgroup allow (2 / 4 measured slower: DESIGN 6.1).  Debug
+        // bits 4-6 = 7: one wave per camera vertex (connect_resolve_wide.hpp: same results bit for bit, measured slower: 1.14 vs
+        // 0.93 ms; a second implementation kept as a cross-check, built only with -DCL2_TEST_VARIANT = libclive2_amd_test.so)
         const int occ = (r->debug_flags >> 4) & 7;
+        if (occ != 0 && occ != 7) return fail(r, CL2_E_INVALID, "debug bits 4-6 must be 0 or 7");
 #ifdef CL2_TEST_VARIANT
         if (occ == 7)
             hipLaunchKernelGGL(k_connect_resolve_wide, dim3((B + RW_PIX - 1) / RW_PIX), dim3(RW_BLOCK), 0, st, B, lp, cp, r->d_mats,
@@ -504,7 +499,7 @@ int launch_resolve(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
 #else
         if (occ == 7) return fail(r, CL2_E_INVALID, "the one-wave-per-camera-vertex resolve kernel is only built into the test variant of the library");
 #endif
-        if (occ == 2) CL2_RESOLVE(2); else if (occ == 4) CL2_RESOLVE(4); else CL2_RESOLVE(3);
+        CL2_RESOLVE(3);
 #undef CL2_RESOLVE
     }
     HIP_TRY(r, hipGetLastError());
@@ -1502,6 +1497,7 @@ int cl2_set_debug_flags(cl2_renderer* r, int flags) {
     if (flags & 7) return fail(r, CL2_E_INVALID, "debug bits 0-2 (skip parts of the resolve stage: invalid renders) exist only in the test variant of the library");
 #endif
     if (flags & ~CL2_DEBUG_KNOWN_BITS) return fail(r, CL2_E_INVALID, "unknown debug flag bits (see include/clive2_amd.h)");
+    if (((flags >> 4) & 7) != 0 && ((flags >> 4) & 7) != 7) return fail(r, CL2_E_INVALID, "debug bits 4-6 must be 0 or 7");
     r->debug_flags = flags;
     r->bvh.n_fast_nodes = ((flags >> 7) & 1) ? 0 : r->n_fast;      // bit 7: walk the full table (A/B of the pruned one)
     return CL2_OK;

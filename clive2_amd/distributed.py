@@ -102,7 +102,12 @@ def join_communicator(renderer, rank, world_size, path=None, timeout=180.0):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC between the ranks' processes on this pool
     n = renderer._L.cl2_comm_unique_id_bytes()
     uid = exchange_unique_id(rank, world_size, renderer.comm_unique_id, n, path=path, timeout=timeout)
-    renderer.comm_init(rank, world_size, uid)
+    try:
+        renderer.comm_init(rank, world_size, uid)
+    except Exception as e:
+        # RCCL's "invalid usage" at this point is almost always two ranks on one device (one GPU per rank is required)
+        raise type(e)(f"{e}  [rank {rank} of {world_size} on device {renderer.device}: every rank needs a GPU of its own -- "
+                      f"RCCL refuses two ranks on one device]") from e
     finish_exchange(rank, path)
 
 

@@ -222,19 +222,18 @@ int cl2_set_counting(cl2_renderer* r, int on);      /* node / triangle test tall
 int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
 /* Launch-organisation switches for experiments and tests.  None of them changes a result.
  *   bit 3       the per-level subpath launches take the 4-wide walk in the serial order too
- *   bits 4-6    variant of the resolve kernel: 2 / 4 = register budget as waves per SIMD; 7 = one wave per camera
- *               vertex (second implementation, only in the test variant of the library)
+ *   bits 4-6    7 = the second implementation of the resolve kernel, one wave per camera vertex (only in the test variant
+ *               of the library); other values are refused
  *   bit 7       walk the full record table of an LDS-resident tree instead of the pruned one
  *   bits 8-10   eighths of the wave slots given to the subpath stage while the sample pipeline runs (0 = tuned)
  *   bit 12      invert the one/two-triangles-per-step choice of the persistent walk
- *   bits 13-15  whole-subpath launch: register budget as waves per SIMD (4, 5, 6; 7 = 8; 0 = default)
  *   bits 16-19  4-wide walk: stack entries per lane in LDS (0 = default 4)
  *   bits 20-23  4-wide walk: LDS window in units of 32 wide nodes (0 = default 2)
  * Any other bit is refused (CL2_E_INVALID).  Bits 0-2 exist ONLY in the test variant of the library
  * (libclive2_amd_test.so, -DCL2_TEST_VARIANT), where they switch parts of the resolve stage off for timing
  * dissections -- bit 0 the t = 1 splat atomics, bit 1 / bit 2 the t >= 2 / t == 1 strategy pairs -- and make the
  * render INVALID; the shipped library refuses them. */
-#define CL2_DEBUG_KNOWN_BITS 0x00FFF7FF
+#define CL2_DEBUG_KNOWN_BITS 0x00FF17FF
 int cl2_set_debug_flags(cl2_renderer* r, int flags);
 /* Whole-subpath launch (traversal mode 4): lanes that must have gathered with a known closest hit before a wave runs
  * its bounce phase, and the steps the first of them waits at most.  0 = default (32 lanes, 48 steps).  Same results. */
