@@ -718,6 +718,8 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
                     const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
                     const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
                     const int ref[4] = {__float_as_int(rf.x), __float_as_int(rf.y), __float_as_int(rf.z), __float_as_int(rf.w)};
+                    int next_ref = WIDE_EMPTY;                         // the slot that would pop first skips the stack (bvh_wide.hpp)
+                    float next_tmin = 0.0f;
 #pragma unroll
                     for (int k = 3; k >= 0; k--) {
                         if (ref[k] == WIDE_EMPTY) continue;
@@ -726,9 +728,14 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
                         const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
                                                            __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
                         const float tmax = __builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
-                        if (tmin <= tmax && tmin < best.t) push(ref[k], tmin);
+                        if (tmin <= tmax && tmin < best.t) {
+                            if (next_ref != WIDE_EMPTY) push(next_ref, next_tmin);
+                            next_ref = ref[k]; next_tmin = tmin;
+                        }
                     }
-                    pop_next();
+                    if (next_ref == WIDE_EMPTY) pop_next();
+                    else if (next_ref >= 0) cur = next_ref;
+                    else { const int info = ~next_ref; tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
                 }
             } else if (tri_i >= tri_end && node < n_nodes) {
                 float4 lo, hi;
