@@ -238,17 +238,15 @@ inline bool split_paths(const cl2_renderer* r) {
 inline bool split_conn(const cl2_renderer* r) {
     return r->traversal_mode >= 2 || (r->traversal_mode == 0 && !tree_in_lds(r));
 }
-// The exact 4-wide walk (bvh_wide.hpp) for the connection-ray launch: mode 5, and the automatic choice for trees that
-// are read through the caches (same 16 MB limit as the two-triangle step): connection launch 5.78 -> 4.89 ms on the
-// glass scene, 6.98 -> 6.02 ms on the blob (sample pipeline: 13.7 -> 12.5 ms, 16.6 -> 15.4 ms).  A 155 MB tree walks
-// slower this way (15.7 -> 18.6 ms: a wide node moves a whole 128-byte line per visit, used or not, and that walk is
-// bound by the bytes that miss L2), so it keeps the binary walk.  Never while counting: the node-test tallies are
-// defined by the binary walk.  The per-level subpath launches use it while the sample pipeline runs (launch_trace).
+// The exact 4-wide walk (bvh_wide.hpp) for the connection-ray launch and, while the sample pipeline runs, the per-level subpath
+// launches: mode 5, and the automatic choice for every tree that is read through the caches.  Round 2 kept the binary walk above
+// 16 MB (15.7 vs 18.6 ms on the 155 MB tree, one triangle per pass); with two triangle pairs per pass, 7 stack entries in LDS and
+// the gathered refill the wide walk is ahead there too (round 3, same box: connection launch 14.08 -> 13.51 ms, sample 27.78 ->
+// 27.22 ms).  Never while counting: the node-test tallies are defined by the binary walk.
 inline bool wide_walk(const cl2_renderer* r) {
     if (r->n_wide <= 0 || r->counting) return false;
     if (r->traversal_mode == 5) return true;
-    const size_t bytes = (size_t)r->bvh.n_nodes * 32 + (size_t)r->bvh.n_tris * 48;
-    return (r->traversal_mode == 0 || r->traversal_mode == 3 || r->traversal_mode == 4) && !tree_in_lds(r) && bytes <= ((size_t)16 << 20);
+    return (r->traversal_mode == 0 || r->traversal_mode == 3 || r->traversal_mode == 4) && !tree_in_lds(r);
 }
 // Whole subpaths (light, then camera, all levels) in ONE persistent launch per sample (k_subpaths_persistent)
 // instead of a traversal + a bounce launch per level and kind: mode 4.  Measured at 1080p (ms per sample, serial order /
@@ -338,8 +336,8 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
     // the binary records (lanes whose ray has a non-finite 1/d) come through the caches: no window for them
     BvhView b = r->bvh;
     b.n_lds_nodes = 0; b.lds_tris = 0; b.n_fast_nodes = 0;
-    if (two_tris_per_step(r)) hipLaunchKernelGGL((k_traverse_wide<true, Source>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn);
-    else hipLaunchKernelGGL((k_traverse_wide<false, Source>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn);
+    // always two triangle pairs per pass: the pass, not the fetch, is the unit of cost of this walk (bvh_wide.hpp)
+    hipLaunchKernelGGL((k_traverse_wide<true, Source>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn);
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;
 }

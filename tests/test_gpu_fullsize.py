@@ -320,7 +320,7 @@ def test_config5_real_size_vs_oracle(interior_real, oracle_mod):
     org = r.organisation()
     assert not org["tree_in_lds"] and org["persistent_subpaths"] and org["persistent_connections"]
     assert org["two_tris_per_step"] == 0 and org["tree_bytes"] > (16 << 20)     # one triangle per step above 16 MB
-    assert org["wide_connections"] == 0 and org["wide_nodes"] > 50000            # available, but the binary walk is faster here
+    assert org["wide_connections"] == 1 and org["wide_nodes"] > 50000            # round 3: the 4-wide walk (two pairs per pass) is ahead on the 155 MB tree too
     assert org["n_records"] > 300000 and org["n_lds_records"] == 512 and 0 < org["n_top_renumbered"] <= 512
     assert 50 < c["box_tests"] / c["counted_rays"] < 65      # N_node 57.6 at 1080p
     # both forms of the persistent step and the one-ray-per-lane organisation give the same subpaths
