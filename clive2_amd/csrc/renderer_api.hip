@@ -324,12 +324,13 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
     // LDS per workgroup: per-lane stack (8 B per entry and lane) + the top of the tree (128 B per wide node); experiment
     // switches: debug_flags bits 16-19 stack entries (0 = default), bits 20-23 window in units of 32 wide nodes
     const int sflag = (r->debug_flags >> 16) & 0xF, wflag = (r->debug_flags >> 20) & 0xF;
-    // round 3: 7 entries + a 32-node window (18 KB per workgroup, 8 workgroups per CU) instead of 4 + 64 (16 KB).  The depth of a
-    // 4-wide walk is mostly 2..6; with 4 entries in LDS some lane of nearly every wave was past them, and its pushes and pops
-    // went to the global overflow array inside the pass (glass 9.23 -> 8.81 ms per sample, blob 12.17 -> 11.51; 6 + 64 and
-    // 8 + 32 measure the same, 8 + 64 and 6 + 96 lose a workgroup per CU: 9.25 / 9.28)
+    // round 3: 7 stack entries + a 64-node window (22 KB per workgroup, 7 workgroups per CU) instead of 4 + 64 (16 KB, 8).  The
+    // depth of a 4-wide walk is mostly 2..6; with 4 entries in LDS some lane of nearly every wave was past them, and its pushes
+    // and pops went to the global overflow array inside the pass.  ms per sample, same box: glass 9.23 -> 8.81 (7 + 32) / 8.86
+    // (7 + 64), blob 12.17 -> 11.51 / 11.57, 1M triangles 27.28 (7 + 32) / 26.48 (7 + 64) / 26.65 (8 + 64) / 26.53 (7 + 96);
+    // on the small trees 8 + 64 and 6 + 96 lose: 9.25 / 9.28
     w.stack_lds = sflag ? std::min(sflag, WIDE_STACK_LDS) : 7;
-    w.n_lds_nodes = std::min(r->n_wide, 32 * (wflag ? wflag : 1));
+    w.n_lds_nodes = std::min(r->n_wide, 32 * (wflag ? wflag : 2));
     // never more than the 64 KB a workgroup may ask for: the window gives way, the stack entries are needed
     w.n_lds_nodes = std::min<int>(w.n_lds_nodes, (int)(((size_t)64 * 1024 - (size_t)w.stack_lds * BLOCK * 8) / 128));
     const size_t lds = (size_t)w.stack_lds * BLOCK * 8 + (size_t)w.n_lds_nodes * 128;

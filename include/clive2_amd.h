@@ -228,7 +228,7 @@ int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
  *   bits 8-10   eighths of the wave slots given to the subpath stage while the sample pipeline runs (0 = tuned)
  *   bit 12      invert the one/two-triangles-per-step choice of the persistent walk
  *   bits 16-19  4-wide walk: stack entries per lane in LDS (0 = default 7; at most 8)
- *   bits 20-23  4-wide walk: LDS window in units of 32 wide nodes (0 = default 1)
+ *   bits 20-23  4-wide walk: LDS window in units of 32 wide nodes (0 = default 2)
  * Any other bit is refused (CL2_E_INVALID).  Bits 0-2 exist ONLY in the test variant of the library
  * (libclive2_amd_test.so, -DCL2_TEST_VARIANT), where they switch parts of the resolve stage off for timing
  * dissections -- bit 0 the t = 1 splat atomics, bit 1 / bit 2 the t >= 2 / t == 1 strategy pairs -- and make the
