@@ -195,8 +195,11 @@ constexpr int RAY_CHUNK_MAX = 512;  // rays handed to a wave per global atomic: 
 // one or two lanes that just finished puts two extra memory round trips on every pass's critical path.  Same-box A/B
 // (tools/exp_ab_scene.py, connection launch alone, ms): 1M triangles, binary walk 15.7 -> 14.5 / 14.0 / 14.0 / 15.8 at
 // 16 / 24 / 32 / 48 lanes; glass, 4-wide walk 3.90 -> 3.81 / 3.86 / 3.80 / 4.14; blob 5.12 -> 5.03 / 5.04 / 5.10 / 6.10.
+#ifndef CL2_REFILL_MIN_WIDE
+#define CL2_REFILL_MIN_WIDE 16
+#endif
 constexpr int REFILL_MIN_BINARY = 24;
-constexpr int REFILL_MIN_WIDE = 16;
+constexpr int REFILL_MIN_WIDE = CL2_REFILL_MIN_WIDE;
 
 template <bool COUNT, bool TWO_TRIS, class Source>
 __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhView& b, unsigned n, unsigned* work_counter,
