@@ -227,6 +227,24 @@ struct PathRaySource {          // subpath rays: queue entry -> pixel -> (P0.xyz
     }
 };
 
+// Two level-0 launches in one: the first rays of the light subpaths (rays [0, B)) and of the camera subpaths (rays [B, 2B)).
+// Traversal needs no random numbers, so the camera subpath's first closest hit does not have to wait for the light subpath's
+// last bounce (its BOUNCE does: one RNG stream per pixel, renderer.py:281-291); the hits of the camera rays go to a buffer of
+// their own and are consumed by the camera subpath's level-0 bounce launch six levels later.  Token: bit 31 = camera.
+struct DualPathRaySource {
+    const float4 *LP0, *LP1, *CP0, *CP1; float4 *hit_light, *hit_camera; int B;
+    __device__ __forceinline__ int load(unsigned j, V3& o, V3& d) const {
+        const bool cam = j >= (unsigned)B;
+        const int p = (int)(cam ? j - (unsigned)B : j);
+        o = v3((cam ? CP0 : LP0)[p]); d = v3((cam ? CP1 : LP1)[p]);
+        return p | (cam ? (int)0x80000000 : 0);
+    }
+    __device__ __forceinline__ void store(int token, const Hit& h) const {
+        float4* dst = token < 0 ? hit_camera : hit_light;
+        dst[token & 0x7FFFFFFF] = make_float4(__int_as_float(h.tri), h.t, h.u, h.v);
+    }
+};
+
 // Closest-hit results of the connection rays: the hit triangle for every slot (all the t >= 2 pairs need,
 // visibility_test compares triangles only) and the distance for the six t = 1 slots (the film projection,
 // world_ray_to_camera_ray, needs it).  One allocation: int tri[36][B] followed by float t1[6][B].

@@ -86,8 +86,9 @@ struct cl2_renderer {
     PathBufs sets[3][2]{};             // subpath buffer sets of the sample pipeline
     int cur = 0;                       // the set stage calls and exports use (after run_samples: the last sample's)
     float4* d_hit = nullptr;
+    float4* d_hit_cam0 = nullptr;      // closest hits of the camera subpaths' first rays, traced together with the light subpaths' (launch_trace)
     int* d_queue = nullptr;            // [6][B], shared by both subpath kinds (they run one after the other)
-    unsigned* d_qcount = nullptr;      // [8]: [0] = B (level-0 count), [1..6] level counts, [7] connection rays
+    unsigned* d_qcount = nullptr;      // [9]: [0] = B (level-0 count), [1..6] level counts, [7] connection rays, [8] = 2B
     int* d_ctag = nullptr;             // connection-ray queue: {slot, pixel} tags
     float2* d_chit[2] = {nullptr, nullptr};            // two sets: connection rays of sample i+1 vs resolve of sample i
     unsigned long long* d_cmask[2] = {nullptr, nullptr};
@@ -345,11 +346,15 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
 
 // Subpath phase scratch (d_queue, d_qcount[0..6], d_work[0..6], d_hit, d_block_stats) is touched by this
 // phase only; the connection phase owns d_qcount[7] and d_work[7].
-int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set) {
+// `cam0`: 0 = plain; 1 (light subpaths) = the level-0 traversal launch also walks the camera subpaths' first rays (their
+// hits go to d_hit_cam0); 2 (camera subpaths) = level 0 has no traversal launch of its own, its bounce reads d_hit_cam0.
+// Only the persistent per-level organisation has separate traversal launches to merge.
+int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set, int cam0 = 0) {
     const int B = r->B;
     PathBufs pb = set[which];
     HIP_TRY(r, hipMemsetAsync(r->d_qcount + 1, 0, 6 * sizeof(unsigned), st));
     const bool split = split_paths(r);
+    if (!split) cam0 = 0;
     if (split) HIP_TRY(r, hipMemsetAsync(r->d_work, 0, 7 * sizeof(unsigned), st));
     const int step = split ? 1 : effective_levels(r);
     for (int first = 0; first < MAX_VERTS; first += step) {
@@ -359,32 +364,43 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
         const unsigned* c_in = r->d_qcount + first;
         int* q_out = r->d_queue + (size_t)(end - 1) * B;
         unsigned* c_out = r->d_qcount + end;
-        if (split) {
+        const bool merged = first == 0 && cam0 == 1, hits_ready = first == 0 && cam0 == 2;
+        if (split && !hits_ready) {
             Timed t(r, ST_TRAVERSE_PATHS, st);
             PathRaySource src{q_in, pb.P0 + (size_t)first * B, pb.P1 + (size_t)first * B, r->d_hit};
+            const PathBufs& cpb = set[CL2_CAMERA];
+            DualPathRaySource dual{pb.P0, pb.P1, cpb.P0, cpb.P1, r->d_hit, r->d_hit_cam0, B};
+            const unsigned* c_trav = merged ? r->d_qcount + 8 : c_in;
             // the per-level subpath launches take the 4-wide walk while the sample pipeline runs: alone they are tail-bound and
             // gain nothing (glass 7.43 -> 7.56 ms), but beside the connection stage what counts is the work they put on
             // the machine (-20 % VALU): 12.43 -> 12.19 ms per sample on the glass scene, 15.38 -> 15.0 on the blob.
             // debug_flags bit 3 forces it in the serial order too (tests)
             if (wide_walk(r) && (r->pipe_active || ((r->debug_flags >> 3) & 1))) {
-                TRY(launch_wide(r, st, 0, c_in, r->d_work + first, src, 0));
+                if (merged) TRY(launch_wide(r, st, 0, c_trav, r->d_work + first, dual, 0));
+                else TRY(launch_wide(r, st, 0, c_trav, r->d_work + first, src, 0));
                 r->launches_tp++;
             } else {
-#define CL2_PERSIST(CNT, TWO)                                                                                              \
-            hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, PathRaySource>), dim3(persistent_grid_paths(r)), dim3(BLOCK), bvh_lds_bytes(r), \
-                               st, r->bvh, c_in, r->d_work + first, src, r->d_stats, 0)
-            if (two_tris_per_step(r)) { if (r->counting) CL2_PERSIST(true, true); else CL2_PERSIST(false, true); }
-            else { if (r->counting) CL2_PERSIST(true, false); else CL2_PERSIST(false, false); }
+#define CL2_PERSIST(CNT, TWO, SRCT, SRC)                                                                                   \
+            hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, SRCT>), dim3(persistent_grid_paths(r)), dim3(BLOCK), bvh_lds_bytes(r), \
+                               st, r->bvh, c_trav, r->d_work + first, SRC, r->d_stats, 0)
+#define CL2_PERSIST_SRC(SRCT, SRC)                                                                                         \
+            do {                                                                                                           \
+                if (two_tris_per_step(r)) { if (r->counting) CL2_PERSIST(true, true, SRCT, SRC); else CL2_PERSIST(false, true, SRCT, SRC); } \
+                else { if (r->counting) CL2_PERSIST(true, false, SRCT, SRC); else CL2_PERSIST(false, false, SRCT, SRC); }       \
+            } while (0)
+            if (merged) CL2_PERSIST_SRC(DualPathRaySource, dual); else CL2_PERSIST_SRC(PathRaySource, src);
+#undef CL2_PERSIST_SRC
 #undef CL2_PERSIST
             r->launches_tp++;
             HIP_TRY(r, hipGetLastError());
             }
         }
         Timed t(r, split ? ST_BOUNCE : ST_TRAVERSE_PATHS, st);
+        const float4* ext_hit = hits_ready ? r->d_hit_cam0 : r->d_hit;
 #define CL2_TRACE(CAM, CNT, EXT)                                                                                          \
         hipLaunchKernelGGL((k_trace_subpath<CAM, CNT, EXT>), dim3(grid_for(B)), dim3(BLOCK), (EXT) ? 0 : bvh_lds_bytes(r), st, r->bvh, r->d_stats, \
                            first, end, q_in, c_in, q_out, c_out, B, pb, r->d_seeds, r->d_tri_shade, r->d_mats, r->n_mats,        \
-                           r->d_block_stats, r->d_hit)
+                           r->d_block_stats, ext_hit)
         if (split) { if (which == CL2_CAMERA) CL2_TRACE(true, false, true); else CL2_TRACE(false, false, true); }
         else if (which == CL2_CAMERA) { if (r->counting) CL2_TRACE(true, true, false); else CL2_TRACE(true, false, false); }
         else { if (r->counting) CL2_TRACE(false, true, false); else CL2_TRACE(false, false, false); }
@@ -398,9 +414,11 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
 // subpaths of every pixel: kinds = 1 light, 2 camera, 3 both (light first: one RNG stream per pixel)
 int launch_subpaths(cl2_renderer* r, hipStream_t st, const PathBufs* set, int kinds) {
     if (!whole_subpaths(r)) {
+        // both kinds in one call (cl2_run_samples): the camera subpaths' first rays ride in the light subpaths' level-0 launch
+        const bool merge = kinds == 3;
         int rc = CL2_OK;
-        if (kinds & 1) rc = launch_trace(r, CL2_LIGHT, st, set);
-        if (rc == CL2_OK && (kinds & 2)) rc = launch_trace(r, CL2_CAMERA, st, set);
+        if (kinds & 1) rc = launch_trace(r, CL2_LIGHT, st, set, merge ? 1 : 0);
+        if (rc == CL2_OK && (kinds & 2)) rc = launch_trace(r, CL2_CAMERA, st, set, merge ? 2 : 0);
         return rc;
     }
     HIP_TRY(r, hipMemsetAsync(r->d_work, 0, sizeof(unsigned), st));
@@ -621,8 +639,9 @@ int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_render
         }
     }
     A(r->d_hit, B);
+    A(r->d_hit_cam0, B);
     A(r->d_queue, MAX_VERTS * B);
-    A(r->d_qcount, 8);
+    A(r->d_qcount, 9);
     A(r->d_work, 8);
     A(r->d_ctag, (size_t)CONN_SLOTS * B);
     for (int q = 0; q < 2; q++) { A(r->d_chit[q], (size_t)CONN_SLOTS * B); A(r->d_cmask[q], B); }
@@ -634,7 +653,7 @@ int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_render
     A(r->d_block_stats, (size_t)grid_for(B) * 4);
 #undef A
     if (rc != CL2_OK) return bail(rc);
-    unsigned qc[8] = {(unsigned)r->B, 0, 0, 0, 0, 0, 0, 0};
+    unsigned qc[9] = {(unsigned)r->B, 0, 0, 0, 0, 0, 0, 0, 2u * (unsigned)r->B};      // [8]: ray count of the merged level-0 launch
     bool ok = hipMemcpy(r->d_qcount, qc, sizeof qc, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemset(r->d_light_image, 0, B * sizeof(float4)) == hipSuccess;
     ok = ok && hipMemset(r->d_finalized, 0, B * sizeof(float4)) == hipSuccess;
