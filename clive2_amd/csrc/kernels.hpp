@@ -827,14 +827,16 @@ __device__ __forceinline__ int conn_slot(int t, int s) { return (t - 1) * 6 + (s
 
 // Cull test for one (t,s) pair, trace.metal:667-688 + :577-584; on success returns the ray.
 struct ConnVtx { V3 o, n; int meta; };
-__device__ __forceinline__ bool conn_ray(int t, const ConnVtx& lv, const ConnVtx& cv, const MaterialDev* mats,
+// `l_specular` / `c_specular`: material type > 0 at the light / camera vertex (looked up once per vertex by the caller: as loads
+// inside the 36-pair loop they were 68 dependent single-dword fetches per thread, each with its own wait).
+__device__ __forceinline__ bool conn_ray(int t, const ConnVtx& lv, const ConnVtx& cv, bool l_specular, bool c_specular,
                                          V3 focal, V3 cam_dir, V3& dir) {
-    if (__float_as_int(mats[lv.meta & 0xFF].color_type.w) > 0) return false;
+    if (l_specular) return false;
     if (t == 1) {
         dir = normalize(focal - lv.o);
         return !(dot(dir, cam_dir) > 0.0f);
     }
-    if (__float_as_int(mats[cv.meta & 0xFF].color_type.w) > 0) return false;
+    if (c_specular) return false;
     dir = normalize(cv.o - lv.o);
     if (dot(lv.n, dir) < DELTA_F) return false;
     if (dot(cv.n, -dir) < DELTA_F) return false;
@@ -846,10 +848,13 @@ __device__ __forceinline__ bool conn_ray(int t, const ConnVtx& lv, const ConnVtx
 // entries are the same (t,s) strategy of neighbouring pixels: the vertex gathers of
 // k_traverse_conn are coalesced and its rays coherent.
 __global__ __launch_bounds__(BLOCK, 6) void k_connect_setup(
-        int B, PathBufs lp, PathBufs cp, const MaterialDev* __restrict__ mats, CameraRec cam,
+        int B, PathBufs lp, PathBufs cp, const MaterialDev* __restrict__ mats, int n_mats, CameraRec cam,
         int* __restrict__ ctag, unsigned* __restrict__ ccount, unsigned long long* __restrict__ cmask) {
     __shared__ unsigned s_wave_total[WAVES_PER_BLOCK];
     __shared__ unsigned s_base;
+    __shared__ int s_mtype[256];                           // material types (the table has at most 256 entries, cl2_upload_scene)
+    for (int i = threadIdx.x; i < n_mats; i += BLOCK) s_mtype[i] = __float_as_int(mats[i].color_type.w);
+    __syncthreads();
     const int pid = blockIdx.x * BLOCK + threadIdx.x;
     const bool valid = pid < B;
     const int Lc = valid ? cp.len[pid] : 0, Ll = valid ? lp.len[pid] : 0;
@@ -857,11 +862,13 @@ __global__ __launch_bounds__(BLOCK, 6) void k_connect_setup(
     const int lane = lane_id(), wave = threadIdx.x >> 6;
 
     ConnVtx lv[MAX_VERTS];
+    unsigned l_spec = 0;
 #pragma unroll
     for (int s = 0; s < MAX_VERTS; s++) {
         if (s < Ll) {
             const float4 a = lp.P0[(size_t)s * B + pid], c = lp.P2[(size_t)s * B + pid];
             lv[s] = ConnVtx{v3(a), v3(c), __float_as_int(c.w)};
+            if (s_mtype[lv[s].meta & 0xFF] > 0) l_spec |= 1u << s;
         } else lv[s] = ConnVtx{v3(0, 0, 0), v3(0, 0, 0), 0};
     }
     // pass 1: predicates
@@ -870,14 +877,16 @@ __global__ __launch_bounds__(BLOCK, 6) void k_connect_setup(
 #pragma unroll
     for (int t = 1; t <= MAX_VERTS; t++) {
         ConnVtx cv{v3(0, 0, 0), v3(0, 0, 0), 0};
+        bool c_specular = false;
         if (t <= Lc) {
             const float4 a = cp.P0[(size_t)(t - 1) * B + pid], c = cp.P2[(size_t)(t - 1) * B + pid];
             cv = ConnVtx{v3(a), v3(c), __float_as_int(c.w)};
+            c_specular = s_mtype[cv.meta & 0xFF] > 0;
         }
 #pragma unroll
         for (int s = 1; s <= MAX_VERTS; s++) {
             V3 dir;
-            const bool pred = (t <= Lc) && (s <= Ll) && conn_ray(t, lv[s - 1], cv, mats, focal, cam_dir, dir);
+            const bool pred = (t <= Lc) && (s <= Ll) && conn_ray(t, lv[s - 1], cv, (l_spec >> (s - 1)) & 1u, c_specular, focal, cam_dir, dir);
             if (pred) mine |= 1ull << conn_slot(t, s);
             wave_total += __popcll(__ballot(pred));
         }

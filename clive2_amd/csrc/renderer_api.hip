@@ -461,8 +461,14 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
     HIP_TRY(r, hipMemsetAsync(r->d_qcount + 7, 0, sizeof(unsigned), st));
     {
         Timed t(r, ST_CONNECT_SETUP, st);
-        hipLaunchKernelGGL(k_connect_setup, dim3(grid_for(B)), dim3(BLOCK), 0, st, B, lp, cp,
-                           r->d_mats, r->cam, r->d_ctag, r->d_qcount + 7, r->d_cmask[cs]);
+        // Large scenes: this launch (8,100 short workgroups at 7 waves per SIMD) runs beside the persistent subpath launches of
+        // the next sample, whose chain is the critical path; left alone it floods the CUs and every level launch of that chain
+        // starts late.  39 KB of unused dynamic LDS hold it to 4 workgroups per CU: glass 8.73 -> 8.46 ms per sample, blob 11.03
+        // -> 10.85 (25 KB: 8.71 / 11.08; 31 KB: 8.44 / 10.98; 52 KB: 8.61 / 10.86).  The Cornell pipeline has no persistent
+        // launches and wants the kernel at full speed.
+        const size_t pad = split_conn(r) ? (size_t)39 * 1024 : 0;
+        hipLaunchKernelGGL(k_connect_setup, dim3(grid_for(B)), dim3(BLOCK), pad, st, B, lp, cp,
+                           r->d_mats, r->n_mats, r->cam, r->d_ctag, r->d_qcount + 7, r->d_cmask[cs]);
     }
     HIP_TRY(r, hipGetLastError());
     {
@@ -1131,21 +1137,32 @@ int tune_levels(cl2_renderer* r, int& done) {
 // their wave slots until they run dry, so the stages get fixed shares (persistent_grid_paths/_conn) -- 3, 4
 // or 5 eighths for the subpath stage, no fixed shares, or the serial order.  The best choice depends on the
 // scene and the frame size; every candidate renders TUNE_SAMPLES samples and is timed on the host.
-constexpr int TUNE_TOTAL = 5 * TUNE_SAMPLES;
+constexpr int TUNE_TOTAL = 7 * TUNE_SAMPLES;
 inline bool shares_untuned(const cl2_renderer* r) { return pipeline_stages(r) != 0 && split_conn(r) && r->paths_share == 0; }
 int tune_shares(cl2_renderer* r, int& done) {
     if (!shares_untuned(r)) return CL2_OK;
-    int best = 4;
-    double best_t = 1e300;
-    for (int e : {3, 4, 5, 8, SHARE_SERIAL}) {
+    const int cand[5] = {3, 4, 5, 8, SHARE_SERIAL};
+    double t_of[5];
+    auto time_one = [&](int e, double& t) -> int {
         r->paths_share = e;
         const auto t0 = std::chrono::steady_clock::now();
         TRY(run_chunk(r, e != SHARE_SERIAL, TUNE_SAMPLES));
-        const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         done += TUNE_SAMPLES;
-        if (t < best_t) { best_t = t; best = e; }
+        return CL2_OK;
+    };
+    for (int k = 0; k < 5; k++) TRY(time_one(cand[k], t_of[k]));
+    // the two best once more: neighbouring shares differ by a few per cent, one timing of six samples by about as much
+    int a = 0, b = 1;
+    if (t_of[b] < t_of[a]) std::swap(a, b);
+    for (int k = 2; k < 5; k++) {
+        if (t_of[k] < t_of[a]) { b = a; a = k; }
+        else if (t_of[k] < t_of[b]) b = k;
     }
-    r->paths_share = best;
+    double ta = 0, tb = 0;
+    TRY(time_one(cand[a], ta));
+    TRY(time_one(cand[b], tb));
+    r->paths_share = (t_of[a] + ta <= t_of[b] + tb) ? cand[a] : cand[b];
     return CL2_OK;
 }
 }  // namespace
@@ -1156,7 +1173,7 @@ int cl2_run_samples(cl2_renderer* r, int n) {
     bool pipe = pipeline_stages(r) != 0 && n > 1;
     int done = 0;
     if (n >= 2) TRY(tune_levels(r, done));
-    // the share tuner runs inside the first LONG call of a scene (its 30 samples are part of the call's n) unless
+    // the share tuner runs inside the first LONG call of a scene (its 42 samples are part of the call's n) unless
     // cl2_tune() ran it before
     if (pipe && n - done >= TUNE_TOTAL + TUNE_SAMPLES + 6) TRY(tune_shares(r, done));
     if (pipe && split_conn(r) && r->paths_share == SHARE_SERIAL) pipe = false;

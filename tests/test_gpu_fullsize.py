@@ -345,15 +345,15 @@ def test_config5_real_size_vs_oracle(interior_real, oracle_mod):
 
 def test_config5_real_size_1080p_and_4k_properties(interior_real):
     """(b) the HIP path at 1920x1080 and at the config's frame, 3840x2160 (8.3 M pixels: 26-bit pixel ids in the
-    connection tags, 36 x 8.3 M result slots), 2 and 1 samples; 48 samples at 1080p let the stage-share tuner run."""
+    connection tags, 36 x 8.3 M result slots), 2 and 1 samples; 56 samples at 1080p let the stage-share tuner run."""
     r, c = _full_frame_properties(interior_real.with_resolution(1920, 1080), 2)
     assert 50 < c["box_tests"] / c["counted_rays"] < 65 and 18 < c["tri_tests"] / c["counted_rays"] < 28
     r.set_counting(False)
-    r.run_samples(48)                                           # >= 42: the share tuner times its candidates
+    r.run_samples(56)                                           # >= 54: the share tuner times its candidates (the best two twice)
     org = r.organisation()
     assert org["paths_share"] in (3, 4, 5, 8, 9)
     img, wts, cnt, uni = r.read_accumulators()
-    assert (cnt == 50).all() and np.isfinite(img).all()
+    assert (cnt == 58).all() and np.isfinite(img).all()
     r.close()
     r4, c4 = _full_frame_properties(interior_real.with_resolution(3840, 2160), 1)
     assert 50 < c4["box_tests"] / c4["counted_rays"] < 65
