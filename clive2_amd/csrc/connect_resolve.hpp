@@ -193,9 +193,9 @@ __device__ __forceinline__ void resolve_pair(
     }
 }
 
-template <int WAVES_PER_SIMD>
+template <int WAVES_PER_SIMD, bool MATS_LDS>
 __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
-        int B, PathBufs lp, PathBufs cp, const MaterialDev* __restrict__ mats,
+        int B, PathBufs lp, PathBufs cp, const MaterialDev* __restrict__ mats_g, int n_mats,
         const float4* __restrict__ tri_shade, CameraRec cam, const unsigned long long* __restrict__ cmask,
         const float2* __restrict__ chit, float* __restrict__ agg, float4* __restrict__ light_image,
         float4* __restrict__ uni_out, Stats* stats, int debug_flags) {
@@ -204,7 +204,15 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
     __shared__ float LNs[3 * MAX_VERTS * BLOCK];       // light vertex normals
     __shared__ float LCs[3 * MAX_VERTS * BLOCK];       // light vertex colours (throughput numerators)
     __shared__ float splat_tab[WAVES_PER_BLOCK * 5 * 64];   // per-wave exchange table of the light-image splat
+    // The material table in LDS (up to LDS_MAT_CAP entries; the reference ships 8): every contributing pair reads a colour or an
+    // emission by the material index of a vertex -- as global loads those were two dependent fetches inside each pair's code.
+    __shared__ MaterialDev s_mats[LDS_MAT_CAP];
     const int tid = threadIdx.x;
+    if (MATS_LDS) {
+        for (int i = tid; i < n_mats; i += BLOCK) s_mats[i] = mats_g[i];
+        __syncthreads();                               // before any thread leaves
+    }
+    const MaterialDev* __restrict__ mats = MATS_LDS ? s_mats : mats_g;     // compile-time choice: plain LDS reads, not generic ones
     const int pid = blockIdx.x * BLOCK + tid;
     if (pid >= B) return;                              // no block-wide barrier below: LDS rows are private per thread
     const int Lc = cp.len[pid], Ll = lp.len[pid];

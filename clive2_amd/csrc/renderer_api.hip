@@ -509,8 +509,8 @@ int launch_resolve(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
     const PathBufs& cp = set[CL2_CAMERA];
     {
         Timed t(r, ST_CONNECT_RESOLVE, st);
-#define CL2_RESOLVE(W)                                                                                                       \
-        hipLaunchKernelGGL(k_connect_resolve<W>, dim3(grid_for(B)), dim3(BLOCK), 0, st, B, lp, cp, r->d_mats, r->d_tri_shade,   \
+#define CL2_RESOLVE(W, ML)                                                                                                       \
+        hipLaunchKernelGGL((k_connect_resolve<W, ML>), dim3(grid_for(B)), dim3(BLOCK), 0, st, B, lp, cp, r->d_mats, r->n_mats, r->d_tri_shade,   \
                            r->cam, r->d_cmask[cs], r->d_chit[cs], r->d_agg, r->d_light_image, r->d_uni, r->d_stats, r->debug_flags)
         // 3 waves per SIMD: what 165 VGPRs and 52 KB of LDS tables per workgroup allow (2 / 4 measured slower: DESIGN 6.1).  Debug
         // bits 4-6 = 7: one wave per camera vertex (connect_resolve_wide.hpp: same results bit for bit, measured slower: 1.14 vs
@@ -526,7 +526,8 @@ int launch_resolve(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
 #else
         if (occ == 7) return fail(r, CL2_E_INVALID, "the one-wave-per-camera-vertex resolve kernel is only built into the test variant of the library");
 #endif
-        CL2_RESOLVE(3);
+        // the material table goes to LDS when it fits LDS_MAT_CAP entries (the reference ships 8): connect_resolve.hpp
+        if (r->n_mats <= LDS_MAT_CAP) CL2_RESOLVE(3, true); else CL2_RESOLVE(3, false);
 #undef CL2_RESOLVE
     }
     HIP_TRY(r, hipGetLastError());
