@@ -40,6 +40,8 @@ struct BvhView {
     int n_fast_nodes;        // records of the pruned table (0: none); only for trees that are wholly staged
     const float4* fast_nodes;   // the tree without the inner records whose test is not worth its cost (cl2_upload_scene):
                                 // same hits for rays with finite 1/d, fewer box tests
+    int fast_flat;              // 1: the pruned table is a plain list of leaves (every record a leaf, skip = index + 1): every lane
+                                // visits the same records in the same order, so the walk's control flow is wave-uniform
 };
 
 constexpr int LDS_NODE_CAP = 512;   // records in the LDS window: at most 512 * 32 B = 16 KB
@@ -136,6 +138,70 @@ __device__ __forceinline__ Hit closest_hit_impl(const BvhLds& s, const BvhView& 
     return best;
 }
 
+// ray_triangle_intersect, trace.metal:117-142, against a fetched record {v0, e1, e2}; keeps the hit on strict t < best.t
+__device__ __forceinline__ void tri_test(V3 o, V3 d, float4 a0, float4 a1, float4 a2, int index, Hit& best) {
+    const V3 e1 = v3(a1), e2 = v3(a2);
+    const V3 h = cross(d, e2);
+    const float f = rcp_exact(dot(e1, h));
+    const V3 sv = o - v3(a0);
+    const float u = f * dot(sv, h);
+    if (!(u < 0 || u > 1)) {
+        const V3 q = cross(sv, e1);
+        const float v = f * dot(d, q);
+        if (!(v < 0 || u + v > 1)) {
+            const float t = f * dot(e2, q);
+            if (t > DELTA_F && t < best.t) { best.tri = index; best.t = t; best.u = u; best.v = v; }
+        }
+    }
+}
+
+// The pruned table of a tiny scene (the Cornell box: three leaves, 16 triangles) has no inner records left: every ray
+// visits record 0, 1, 2, ... in that order, whatever it hits.  The per-lane walk above then spends vector instructions on
+// bookkeeping that is the same in every lane (record index, triangle index, loop tests, LDS addresses) and waits for each
+// triangle's LDS reads right before it uses them.  Here the two loops run on the scalar unit, a lane that fails a leaf's
+// box test is masked for that leaf's triangles, and the next triangle's record is fetched while the current one is tested.
+// Per lane the sequence of box tests, triangle tests and comparisons is exactly that of closest_hit_impl<.., true, true>
+// on the same table.  Only for waves whose rays all have finite 1/d (v_min / v_max slab test), never while counting.
+__device__ __forceinline__ Hit closest_hit_flat(const BvhLds& s, const BvhView& b, V3 o, V3 d, V3 inv) {
+    Hit best{-1, __builtin_inff(), 0.0f, 0.0f};
+    const int n = b.n_fast_nodes;
+    for (int node = 0; node < n; node++) {
+        const float4 lo = s.fast_nodes[2 * node], hi = s.fast_nodes[2 * node + 1];
+        const float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
+        const float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
+        const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                                           __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
+        const float tmax = __builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
+        const bool in = tmin <= tmax && tmin < best.t;
+        if (!__any(in)) continue;
+        const int info = __builtin_amdgcn_readfirstlane(__float_as_int(hi.w));      // the same word in every lane
+        const int left = info >> 4, right = left + (info & 15) + 1;
+        // Two register sets in turn: the record of triangle i + 1 is on its way while triangle i is tested.  The fetch is
+        // unconditional (the leaf's last triangle fetches itself again): a branch around it makes the compiler wait for ALL
+        // outstanding LDS reads at the join instead of counting them.  keep4() makes the unused fourth word of a record live,
+        // so that each float4 comes by one ds_read_b128 (4 LDS cycles) and not by the ds_read_b96 the compiler would narrow
+        // it to (8 LDS cycles, MI355X_MICROARCH.md "LDS").
+        auto keep4 = [](float4& v) { asm volatile("" : "+v"(v.w)); };
+        auto fetch = [&](int k, float4& r0, float4& r1, float4& r2) {
+            r0 = s.tris[3 * k]; r1 = s.tris[3 * k + 1]; r2 = s.tris[3 * k + 2];
+        };
+        const int last = right - 1;
+        float4 a0, a1, a2, c0, c1, c2;
+        fetch(left, a0, a1, a2);
+        for (int i = left;;) {
+            fetch(i < last ? i + 1 : last, c0, c1, c2);
+            if (in) tri_test(o, d, a0, a1, a2, i, best);
+            keep4(a0); keep4(a1); keep4(a2);        // here, where the record has been consumed: the asm waits for its operand
+            if (++i > last) break;
+            fetch(i < last ? i + 1 : last, a0, a1, a2);
+            if (in) tri_test(o, d, c0, c1, c2, i, best);
+            keep4(c0); keep4(c1); keep4(c2);
+            if (++i > last) break;
+        }
+    }
+    return best;
+}
+
 __device__ __forceinline__ bool finite3(V3 a) {
     return __builtin_fabsf(a.x) < __builtin_inff() && __builtin_fabsf(a.y) < __builtin_inff() && __builtin_fabsf(a.z) < __builtin_inff();
 }
@@ -148,6 +214,7 @@ __device__ __forceinline__ Hit closest_hit(const BvhLds& s, const BvhView& b, V3
     const bool fast = __all(finite3(inv));
     if (all_lds) {
         // the pruned table: not while counting (the tallies are those of the full walk)
+        if (fast && !COUNT && b.n_fast_nodes && b.fast_flat) return closest_hit_flat(s, b, o, d, inv);
         if (fast && !COUNT && b.n_fast_nodes) return closest_hit_impl<COUNT, true, true>(s, b, o, d, inv, n_box, n_tri, s.fast_nodes, b.n_fast_nodes);
         if (fast) return closest_hit_impl<COUNT, true, true>(s, b, o, d, inv, n_box, n_tri, s.nodes, b.n_nodes);
         return closest_hit_impl<COUNT, true, false>(s, b, o, d, inv, n_box, n_tri, s.nodes, b.n_nodes);
@@ -170,23 +237,6 @@ __device__ __forceinline__ Hit closest_hit(const BvhLds& s, const BvhView& b, V3
 // one global atomic per chunk), so all 64 lanes stay busy until the launch runs dry.  The sequence
 // of node visits, triangle tests and comparisons of each ray is exactly that of closest_hit_impl.
 namespace cl2 {
-
-// ray_triangle_intersect, trace.metal:117-142, against a pre-fetched record {v0, e1, e2}; keeps the hit on strict t < best.t
-__device__ __forceinline__ void tri_test(V3 o, V3 d, float4 a0, float4 a1, float4 a2, int index, Hit& best) {
-    const V3 e1 = v3(a1), e2 = v3(a2);
-    const V3 h = cross(d, e2);
-    const float f = rcp_exact(dot(e1, h));
-    const V3 sv = o - v3(a0);
-    const float u = f * dot(sv, h);
-    if (!(u < 0 || u > 1)) {
-        const V3 q = cross(sv, e1);
-        const float v = f * dot(d, q);
-        if (!(v < 0 || u + v > 1)) {
-            const float t = f * dot(e2, q);
-            if (t > DELTA_F && t < best.t) { best.tri = index; best.t = t; best.u = u; best.v = v; }
-        }
-    }
-}
 
 constexpr int RAY_CHUNK_MAX = 512;  // rays handed to a wave per global atomic: 64..512, about a quarter of a wave's fair share
 // Lanes whose ray is finished take a new one only when at least REFILL_MIN of them are idle (or nobody is walking).  The

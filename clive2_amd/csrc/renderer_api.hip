@@ -75,6 +75,7 @@ struct cl2_renderer {
     float4* d_wide = nullptr;
     int n_wide = 0;
     int n_fast = 0;                      // records of the pruned table (bvh.n_fast_nodes unless debug_flags bit 7 switches it off)
+    int fast_flat = 0;                   // the pruned table is a plain list of leaves (bvh.fast_flat unless debug_flags bit 11 switches it off)
     float4* d_fast = nullptr;            // pruned record table of an LDS-resident tree (cl2_upload_scene); bvh.n_fast_nodes == 0: none
     WideView wide{};
     int2* d_wide_ovf = nullptr;          // per-lane stack overflow of the wide launches (one region per stage: [2]); allocated by the first wide launch
@@ -1007,6 +1008,16 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
         r->bvh.fast_nodes = r->d_fast; r->bvh.n_fast_nodes = ((r->debug_flags >> 7) & 1) ? 0 : n_fast;
     }
     r->n_fast = n_fast;
+    // a table without inner records, every skip link pointing at the next record: all rays visit the same records in the
+    // same order and the walk's control flow can be wave-uniform (closest_hit_flat)
+    r->fast_flat = n_fast > 0 ? 1 : 0;
+    for (int j = 0; j < n_fast; j++) {
+        int skip, info;
+        std::memcpy(&skip, &h_fast[2 * (size_t)j].w, 4);
+        std::memcpy(&info, &h_fast[2 * (size_t)j + 1].w, 4);
+        if (info < 0 || skip != j + 1) r->fast_flat = 0;
+    }
+    r->bvh.fast_flat = ((r->debug_flags >> 11) & 1) ? 0 : r->fast_flat;
     r->n_mats = n_mats; r->light_count = light_count; r->cam = cam;
     r->n_top = n_top;
     r->scene_ok = true;
@@ -1540,6 +1551,7 @@ int cl2_set_debug_flags(cl2_renderer* r, int flags) {
     if (((flags >> 4) & 7) != 0 && ((flags >> 4) & 7) != 7) return fail(r, CL2_E_INVALID, "debug bits 4-6 must be 0 or 7");
     r->debug_flags = flags;
     r->bvh.n_fast_nodes = ((flags >> 7) & 1) ? 0 : r->n_fast;      // bit 7: walk the full table (A/B of the pruned one)
+    r->bvh.fast_flat = ((flags >> 11) & 1) ? 0 : r->fast_flat;     // bit 11: per-lane walk of a flat pruned table (A/B of the wave-uniform one)
     return CL2_OK;
 }
 int cl2_set_subpath_gather(cl2_renderer* r, int lanes, int wait_steps) {

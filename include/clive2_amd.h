@@ -226,6 +226,8 @@ int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
  *               of the library); other values are refused
  *   bit 7       walk the full record table of an LDS-resident tree instead of the pruned one
  *   bits 8-10   eighths of the wave slots given to the subpath stage while the sample pipeline runs (0 = tuned)
+ *   bit 11      walk a pruned table that is a plain list of leaves per lane instead of wave-uniformly (csrc/bvh_traverse.hpp,
+ *               closest_hit_flat)
  *   bit 12      invert the one/two-triangles-per-step choice of the persistent walk
  *   bits 16-19  4-wide walk: stack entries per lane in LDS (0 = default 7; at most 8)
  *   bits 20-23  4-wide walk: LDS window in units of 32 wide nodes (0 = default 2)
@@ -233,7 +235,7 @@ int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
  * (libclive2_amd_test.so, -DCL2_TEST_VARIANT), where they switch parts of the resolve stage off for timing
  * dissections -- bit 0 the t = 1 splat atomics, bit 1 / bit 2 the t >= 2 / t == 1 strategy pairs -- and make the
  * render INVALID; the shipped library refuses them. */
-#define CL2_DEBUG_KNOWN_BITS 0x00FF17FF
+#define CL2_DEBUG_KNOWN_BITS 0x00FF1FFF
 int cl2_set_debug_flags(cl2_renderer* r, int flags);
 /* Whole-subpath launch (traversal mode 4): lanes that must have gathered with a known closest hit before a wave runs
  * its bounce phase, and the steps the first of them waits at most.  0 = default (32 lanes, 48 steps).  Same results. */

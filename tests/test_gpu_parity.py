@@ -571,6 +571,31 @@ def test_pruned_table_is_equivalent(scene_name, mode, request, oracle_mod):
     r.close(); full.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_flat_pruned_table_walk_is_equivalent(mode, cornell_small, oracle_mod):
+    """The Cornell box's pruned table is a plain list of its 3 leaves, so every ray visits the same records in the same
+    order and the walk runs with wave-uniform control flow (scalar loops, a leaf's misses masked, the next triangle's
+    record fetched while the current one is tested: closest_hit_flat).  Same subpaths, seeds, aggregators and image as the
+    per-lane walk of the same table (debug bit 11) and as the oracle."""
+    r, o = _pair(cornell_small, oracle_mod)
+    lane, _ = _pair(cornell_small, oracle_mod)
+    lane.set_debug_flags(1 << 11)
+    assert r.organisation()["pruned_records"] == lane.organisation()["pruned_records"] == 3
+    r.set_traversal_mode(mode); lane.set_traversal_mode(mode)
+    _run_to_paths(r, o)
+    lane.make_light_rays(); lane.make_camera_rays(); lane.trace_light_rays(); lane.trace_camera_rays()
+    for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
+        assert r.export_paths(which).tobytes() == ref.tobytes() == lane.export_paths(which).tobytes()
+    _run_rest(r, o)
+    lane.join_paths(); lane.finalize_samples(); lane.gather_light_image(); lane.process_images()
+    assert r.export_aggregators().tobytes() == lane.export_aggregators().tobytes()
+    r.run_samples(3); lane.run_samples(3)
+    assert np.array_equal(r.get_random_buffer(), lane.get_random_buffer())
+    assert r.read_accumulators()[3].tobytes() == lane.read_accumulators()[3].tobytes()       # unidirectional image: no atomics
+    assert r.counters()["rays"] == lane.counters()["rays"]
+    r.close(); lane.close()
+
+
 def test_scene_near_the_lds_caps_keeps_its_residency(oracle_mod):
     """the pruned table shares the workgroup's LDS with the full record table, the staged triangles and the
     subpath kernel's 9.7 KB of shading tables.  Near the 512-record / 512-triangle caps it is left out when it would
