@@ -66,7 +66,7 @@ EXPORTS = [
     "cl2_comm_allreduce_f64", "cl2_comm_destroy", "cl2_import_sample_images", "cl2_query_organisation", "cl2_set_profiling", "cl2_set_counting", "cl2_set_debug_flags", "cl2_read_counters",
     "cl2_reset_counters", "cl2_selftest_exact_math", "cl2_export_rays", "cl2_export_paths", "cl2_export_aggregators",
     "cl2_export_sample_images", "cl2_probe_traverse", "cl2_probe_math", "cl2_probe_bounce",
-    "cl2_tune", "cl2_set_subpath_gather", "cl2_comm_abort",
+    "cl2_tune", "cl2_set_subpath_gather", "cl2_comm_abort", "cl2_tone_log_sum", "cl2_tone_map",
 ]
 
 
@@ -123,6 +123,8 @@ def lib(variant=None):
         L.cl2_comm_allreduce_f64.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]
         L.cl2_tune.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.cl2_set_subpath_gather.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.cl2_tone_log_sum.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        L.cl2_tone_map.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_size_t]
         for name in ("cl2_reduce_accumulators", "cl2_comm_destroy", "cl2_comm_abort", "cl2_synchronize"):
             getattr(L, name).argtypes = [C.c_void_p]
         _libs[variant] = L

@@ -18,6 +18,7 @@
 
 #include "../../include/clive2_amd.h"
 #include "kernels.hpp"
+#include "tonemap.hpp"
 #include "bvh_builder.hpp"
 #include "comm_rccl.hpp"
 #include "comm_wait.hpp"
@@ -97,6 +98,8 @@ struct cl2_renderer {
     float4 *d_light_image = nullptr, *d_finalized = nullptr, *d_uni = nullptr;
     float* d_sample_w = nullptr;
     float* d_acc = nullptr;            // [8][B]
+    double* d_tone_partial = nullptr;  // device tone map: per-workgroup partial sums + the total (allocated by the first call)
+    uint8_t* d_tone_out = nullptr;     // device tone map: the uint8 picture before it is copied out
     Stats* d_stats = nullptr;
     unsigned long long* d_block_stats = nullptr;   // [grid][4]: rays, box tests, tri tests, counted rays per workgroup slot
 
@@ -1249,6 +1252,45 @@ static int acc_copy(cl2_renderer* r, void* dst, const void* src, size_t n_floats
 }
 int cl2_read_accumulators_packed(cl2_renderer* r, float* dst, size_t n) { return acc_copy(r, dst, r ? r->d_acc : nullptr, n, hipMemcpyDeviceToHost); }
 int cl2_write_accumulators_packed(cl2_renderer* r, const float* src, size_t n) { return acc_copy(r, r ? r->d_acc : nullptr, src, n, hipMemcpyHostToDevice); }
+
+// ---------------------------------------------------------------- output stage: tone map on the device (csrc/tonemap.hpp)
+namespace {
+int tone_buffers(cl2_renderer* r) {
+    if (!r->d_tone_partial) TRY(dev_alloc(r, &r->d_tone_partial, (size_t)TONE_BLOCKS + 1));
+    if (!r->d_tone_out) TRY(dev_alloc(r, &r->d_tone_out, (size_t)3 * r->B));
+    return CL2_OK;
+}
+}  // namespace
+
+int cl2_tone_log_sum(cl2_renderer* r, int which, double* sum_out) {
+    if (!r || !sum_out) return CL2_E_INVALID;
+    if (which < 0 || which > 2) return fail(r, CL2_E_INVALID, "picture: 0 image, 1 unweighted_image, 2 unidirectional_image");
+    HIP_TRY(r, hipSetDevice(r->device));
+    TRY(drain(r));
+    TRY(tone_buffers(r));
+    const int grid = std::min(grid_for(r->B), TONE_BLOCKS);
+    hipLaunchKernelGGL(k_tone_logsum, dim3(grid), dim3(256), 0, r->stream, r->d_acc, r->B, which, r->d_tone_partial);
+    hipLaunchKernelGGL(k_tone_logsum_final, dim3(1), dim3(256), 0, r->stream, r->d_tone_partial, grid, r->d_tone_partial + TONE_BLOCKS);
+    HIP_TRY(r, hipGetLastError());
+    HIP_TRY(r, hipMemcpyAsync(sum_out, r->d_tone_partial + TONE_BLOCKS, sizeof(double), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    return CL2_OK;
+}
+
+int cl2_tone_map(cl2_renderer* r, int which, double exposure, double white_point, double log_average, uint8_t* out_bgr, size_t n_bytes) {
+    if (!r || !out_bgr) return CL2_E_INVALID;
+    if (which < 0 || which > 2) return fail(r, CL2_E_INVALID, "picture: 0 image, 1 unweighted_image, 2 unidirectional_image");
+    if (n_bytes != (size_t)3 * r->B) return fail(r, CL2_E_INVALID, "the tone-mapped picture holds 3*W*H bytes");
+    HIP_TRY(r, hipSetDevice(r->device));
+    TRY(drain(r));
+    TRY(tone_buffers(r));
+    hipLaunchKernelGGL(k_tone_apply, dim3(grid_for(r->B)), dim3(256), 0, r->stream, r->d_acc, r->B, which, exposure, white_point * white_point,
+                       log_average, r->d_tone_out);
+    HIP_TRY(r, hipGetLastError());
+    HIP_TRY(r, hipMemcpyAsync(out_bgr, r->d_tone_out, n_bytes, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    return CL2_OK;
+}
 
 // ---------------------------------------------------------------- multi-GPU: RCCL behind the C ABI
 namespace {

@@ -42,6 +42,8 @@ def main(argv=None):
     ap.add_argument("--movie-frames", type=int, default=120)
     ap.add_argument("--start-frame", type=int, default=0)
     ap.add_argument("--out-root", type=str, default="../output")
+    ap.add_argument("--host-tonemap", action="store_true",
+                    help="tone-map every frame on the host with numpy (the reference's path, Renderer.image) instead of on the device")
     args = ap.parse_args(argv)
 
     rank, local_rank, world = rank_info()
@@ -62,7 +64,8 @@ def main(argv=None):
                 raise
             renderer = Renderer(scene, device=0)     # the launcher exposes one GPU per rank: it is device 0
         renderer.run_samples(args.samples)
-        save_frame(os.path.join(out_dir, f"frame_{f:04d}.png"), renderer.image)
+        # a frame leaves the device tone-mapped (6 MB at 1080p; Renderer.image reads 66 MB of accumulators and maps them with numpy)
+        save_frame(os.path.join(out_dir, f"frame_{f:04d}.png"), renderer.image if args.host_tonemap else renderer.tone_mapped("image"))
         del renderer, scene
         print(f"Frame {f} time: {time.time() - t0:.3f}", flush=True)
     return 0

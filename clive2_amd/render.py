@@ -28,6 +28,8 @@ def main(argv=None):
     ap.add_argument("--scene", type=str, default="empty")
     ap.add_argument("--out", type=str, default="render.png")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--device-tonemap", action="store_true",
+                    help="tone-map on the device (Renderer.tone_mapped) instead of on the host with numpy (Renderer.image, the reference's path)")
     args = ap.parse_args(argv)
 
     rank, local_rank, world = rank_info()
@@ -73,7 +75,7 @@ def main(argv=None):
     # Tone-mapped uint8, BGR.  The film sits BEHIND the pinhole, so the picture on it is already upright
     # when read row 0 first (row 0 looks up at the ceiling light): the reference hands `renderer.image`
     # to cv2 unflipped (render.py:35-37).  Only the channel order changes for a PNG (BGR -> RGB).
-    image = renderer.image
+    image = renderer.tone_mapped("image") if args.device_tonemap else renderer.image
     renderer.close()
     try:
         from PIL import Image

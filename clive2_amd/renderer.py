@@ -176,6 +176,23 @@ class Renderer:
     def image(self):
         return tone_map(self.radiance, exposure=4.0)
 
+    _PICTURES = {"image": 0, "unweighted_image": 1, "unidirectional_image": 2}
+
+    def tone_mapped(self, which="image", exposure=4.0, white_point=1.0):
+        """`tone_map` (camera.py:73-82) of one of the three pictures of renderer.py:293-316, computed ON THE DEVICE from
+        the accumulators (cl2_tone_log_sum + cl2_tone_map, csrc/tonemap.hpp): uint8 (H,W,3), BGR.  Only the 3*W*H bytes
+        of the picture cross PCIe (the host path reads the 32*W*H bytes of the accumulators and maps them with numpy).
+        Same arithmetic and dtypes as the host path; the float64 log-luminance sum is added in another order, so a byte
+        can differ from `.image` where 255*x/(x+w) lies within ~1e-13 of an integer."""
+        w = self._PICTURES[which]
+        s = C.c_double(0.0)
+        self._check(self._L.cl2_tone_log_sum(self._h, w, C.byref(s)), "cl2_tone_log_sum")
+        log_avg = np.exp(np.float64(s.value) / (self.pixel_height * self.pixel_width))       # Lw, with numpy's exp
+        out = np.empty((self.pixel_height, self.pixel_width, 3), np.uint8)
+        self._check(self._L.cl2_tone_map(self._h, w, float(exposure), float(white_point), float(log_avg), ptr(out),
+                                         C.c_size_t(out.size)), "cl2_tone_map")
+        return out
+
     @property
     def unweighted_image(self):
         return tone_map(np.nan_to_num(self.read_accumulators()[0], neginf=0, posinf=0), exposure=4.0)

@@ -157,6 +157,22 @@ int cl2_set_pipelining(cl2_renderer* r, int stages);
 int cl2_read_accumulators(cl2_renderer* r, float* summed_image /*H*W*3*/, float* summed_sample_weights /*H*W*/,
                           int32_t* summed_sample_counts /*H*W*/, float* unidirectional /*H*W*3*/, size_t n_pixels);
 int cl2_reset_accumulators(cl2_renderer* r);
+/* -- output stage on the device: the tone map of src/camera.py:73-82 applied to one of the three pictures of
+ *    src/renderer.py:293-316, straight from the accumulators (6 MB instead of 66 MB leave the device per 1080p frame;
+ *    the host does no per-pixel work).  which: 0 `image` (summed_image / summed_sample_weights), 1 `unweighted_image`,
+ *    2 `unidirectional_image`; all scrubbed with nan_to_num(neginf=0, posinf=0) and computed in the dtypes numpy's
+ *    promotion gives the reference (csrc/tonemap.hpp).
+ *      cl2_tone_log_sum   sum over the pixels of log(0.1 + luma) in float64 (the reference: np.sum(log_tone_sums));
+ *                         the caller forms Lw = exp(sum / (H*W)) -- with numpy's exp if it wants numpy's last bit
+ *      cl2_tone_map       (255 * result / (result + white_point^2)).astype(uint8), result = image * exposure / Lw, as
+ *                         H*W*3 bytes, b, g, r per pixel
+ *    Deterministic (fixed reduction tree).  The float64 sum is added in another order than numpy's pairwise sum, so Lw
+ *    can differ from the host path's in its last bits; a byte of the picture changes only where 255*x/(x+w) lies within
+ *    ~1e-13 of an integer.  `Renderer.image` keeps the host path (byte-exact against the reference's fixture);
+ *    `Renderer.tone_mapped()` and movie.py use this one. -- */
+int cl2_tone_log_sum(cl2_renderer* r, int which, double* sum_out);
+int cl2_tone_map(cl2_renderer* r, int which, double exposure, double white_point, double log_average /* Lw */,
+                 uint8_t* out_bgr, size_t n_bytes /* 3*H*W */);
 /* packed planar form [8][H*W] = image b,g,r | weights | unidirectional b,g,r | counts(float):
  * the message of the multi-GPU sum-reduce, as host arrays (checkpointing, CPU-side tests). */
 int cl2_read_accumulators_packed(cl2_renderer* r, float* host_dst, size_t n_floats);

@@ -460,6 +460,47 @@ def test_process_images_and_image_properties_match_reference_fixture():
     assert r.samples == 0 and r.counters()["samples"] == 3
 
 
+def test_device_tone_map_matches_reference_fixture_and_host_path(cornell_small):
+    """cl2_tone_log_sum + cl2_tone_map (csrc/tonemap.hpp) against (a) the three pictures the REFERENCE's own
+    `tone_map` made of the fixture's accumulators (tests/golden/renderer_glue.npz: NaN / +-inf / zero-weight entries
+    included) and (b) the host path `Renderer.image` on a real render.  Same arithmetic and numpy dtypes; the float64
+    log-luminance sum is added in another order than numpy's pairwise sum, so Lw may differ in its last bits and a byte
+    may move where 255*x/(x+w) lies within ~1e-13 of an integer: at most one count, in at most 2 bytes per picture."""
+    import os
+    import clive2_amd as c2
+    from clive2_amd.renderer import Renderer, make_seeds
+
+    def close_enough(got, want):
+        assert got.shape == want.shape and got.dtype == want.dtype == np.uint8
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        assert d.max() <= 1 and int((d > 0).sum()) <= 2, (int(d.max()), int((d > 0).sum()))
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "renderer_glue.npz"))
+    W, H = int(g["width"]), int(g["height"])
+    r = Renderer(c2.create_scene_from_preset("empty", W, H))
+    for k in range(len(g["in_finalized"])):
+        light = g["in_light"][k].copy()
+        light[:, 3] = 0.0
+        r.import_sample_images(finalized=g["in_finalized"][k], light=light, sample_weights=g["in_weights"][k],
+                               unidirectional=g["in_unidirectional"][k])
+        r.process_images()
+    for which in ("image", "unweighted_image", "unidirectional_image"):
+        close_enough(r.tone_mapped(which), g[which])
+    # other exposure / white point than the properties use: against the host function on the same accumulators
+    from clive2_amd.camera import tone_map
+    close_enough(r.tone_mapped("image", exposure=2.0, white_point=1.5), tone_map(r.radiance, exposure=2.0, white_point=1.5))
+    r.close()
+
+    r = Renderer(cornell_small, seeds=make_seeds(cornell_small.pixel_width * cornell_small.pixel_height))
+    r.run_samples(6)
+    for which in ("image", "unweighted_image", "unidirectional_image"):
+        got = r.tone_mapped(which)
+        close_enough(got, getattr(r, which))
+        assert got.std() > 5                              # a picture, not a constant
+    assert r.tone_mapped("image").tobytes() == r.tone_mapped("image").tobytes()        # deterministic
+    r.close()
+
+
 def test_movie_cli_writes_turntable_frames(tmp_path):
     """The reference's turntable loop (movie.py:29-55): one scene + renderer per frame, one PNG each."""
     from clive2_amd import movie
