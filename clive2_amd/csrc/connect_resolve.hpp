@@ -21,6 +21,20 @@
 
 namespace cl2 {
 
+// The triangles of the camera quad (is_camera, scene.py): the t = 1 pairs ask whether the triangle their ray hit is one of
+// them.  As a look-up in the shading records (tri_shade[4 i + 2].w) that was a dependent load -- a memory round trip of its
+// own -- inside each of the six t = 1 pairs; the reference's scenes have two such triangles, which travel as kernel arguments.
+// More than CAM_TRI_ARGS of them: n < 0 and the look-up stays.
+constexpr int CAM_TRI_ARGS = 4;
+struct CamTris { int n; int idx[CAM_TRI_ARGS]; };
+__device__ __forceinline__ bool is_camera_tri(const CamTris& ct, const float4* __restrict__ tri_shade, int i) {
+    if (ct.n < 0) return __float_as_int(tri_shade[4 * i + 2].w) != 0;
+    bool hit = false;
+#pragma unroll
+    for (int k = 0; k < CAM_TRI_ARGS; k++) hit = hit || (k < ct.n && i == ct.idx[k]);
+    return hit;
+}
+
 struct LightVtx {          // the part of a light vertex every pair touches: registers
     V3 o;
     float c, l, tot, cosv;
@@ -40,7 +54,7 @@ __device__ __forceinline__ void resolve_pair(
         // camera junction vertex t-1 and per-path camera tables (LDS)
         V3 c_o_in, V3 c_n_in, float c_c, float c_l, float c_tot_in, float c_cos_in, int c_tri, int c_meta,
         V3 prior_camera_color, const float* GCs, const float* RCs /* [m*BLOCK + tid] */, const float* LNs, const float* LCs,
-        unsigned long long mask, float2 h, const float4* __restrict__ tri_shade,
+        unsigned long long mask, float2 h, const float4* __restrict__ tri_shade, const CamTris& cam_tris,
         const MaterialDev* __restrict__ mats, const CameraRec& cam, V3 focal, V3 cam_dir,
         V3& total, float& contrib_weight_sum, float4* __restrict__ light_image, float* splat_tab, int debug_flags) {
     const int tid = threadIdx.x;
@@ -59,7 +73,7 @@ __device__ __forceinline__ void resolve_pair(
         if (best_i == -1) return;                                             // :193 / :593
         if (t == 1) {
             // world_ray_to_camera_ray, :595-616
-            if (__float_as_int(tri_shade[4 * best_i + 2].w) == 0) return;     // !is_camera
+            if (!is_camera_tri(cam_tris, tri_shade, best_i)) return;         // !is_camera
             const V3 tdir = normalize(focal - a.o);
             const V3 camera_point = a.o + h.y * tdir;
             const float x = dot(camera_point - cam3(cam.center), cam3(cam.dx));
@@ -196,7 +210,7 @@ __device__ __forceinline__ void resolve_pair(
 template <int WAVES_PER_SIMD, bool MATS_LDS>
 __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
         int B, PathBufs lp, PathBufs cp, const MaterialDev* __restrict__ mats_g, int n_mats,
-        const float4* __restrict__ tri_shade, CameraRec cam, const unsigned long long* __restrict__ cmask,
+        const float4* __restrict__ tri_shade, CamTris cam_tris, CameraRec cam, const unsigned long long* __restrict__ cmask,
         const float2* __restrict__ chit, float* __restrict__ agg, float4* __restrict__ light_image,
         float4* __restrict__ uni_out, Stats* stats, int debug_flags) {
     __shared__ float GCs[(MAX_VERTS - 1) * BLOCK];     // GC[v] = G(camera[v], camera[v+1])
@@ -228,6 +242,38 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
     V3 cam_prev_o = v3(0, 0, 0);
     float cam_prev_cos = 0.0f, cam_prev_l = 0.0f, cam_prev_c = 0.0f, cam_prev_G = 0.0f;
 
+    // ---- the whole light subpath is fetched back to back (with each vertex's loads inside its own `if (v < Ll)` the kernel
+    // made a memory round trip per light vertex), and each iteration of the t loop fetches its camera vertex and the
+    // closest-hit results of its pairs together (they were two round trips).  With the is_camera flags as kernel arguments
+    // that is 8 dependent round trips per pixel instead of 25.  Measured: resolve 0.838 -> 0.822 ms -- the kernel waits for
+    // its dependent ARITHMETIC (division chains at three waves per SIMD) more than for memory; fetching the first camera
+    // vertex up here as well costs 168 VGPRs + 16 B of scratch and is slower (0.87 ms).  A vertex slot is fetched when SOME
+    // lane of the wave has it (open scenes: most subpaths are short). ----
+    float4 La[MAX_VERTS], Lb[MAX_VERTS], Lcn[MAX_VERTS], Ld[MAX_VERTS];
+    int Lt[MAX_VERTS];
+#pragma unroll
+    for (int v = 0; v < MAX_VERTS; v++) {
+        if (__builtin_amdgcn_ballot_w64(v < Ll) != 0ull) {
+            const size_t k = (size_t)v * B + pid;
+            La[v] = lp.P0[k]; Lb[v] = lp.P1[k]; Lcn[v] = lp.P2[k]; Ld[v] = lp.P3[k]; Lt[v] = lp.tri[k];
+        } else {
+            La[v] = Lb[v] = Lcn[v] = Ld[v] = make_float4(0, 0, 0, 0); Lt[v] = -1;
+        }
+    }
+    float4 cP0 = make_float4(0, 0, 0, 0), cP1 = cP0, cP2 = cP0, cP3 = cP0;
+    int c_tri = -1;
+    float2 hits[MAX_VERTS + 1];
+    auto load_camera_vertex = [&](int t) {         // camera vertex t-1 and the results of the connection rays that end at it
+        const size_t ck = (size_t)(t - 1) * B + pid;
+        cP0 = cp.P0[ck]; cP1 = cp.P1[ck]; cP2 = cp.P2[ck]; cP3 = cp.P3[ck];
+        c_tri = cp.tri[ck];
+#pragma unroll
+        for (int s = 1; s <= MAX_VERTS; s++) hits[s] = chit_load(chit, B, t, s, pid);
+    };
+    hits[0] = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int s = 1; s <= MAX_VERTS; s++) hits[s] = make_float2(0.0f, 0.0f);
+
     // ---- light subpath -> registers; adjacent geometry terms and interior ratios ----
     LightVtx lv[MAX_VERTS];
     float GL[MAX_VERTS], RL[MAX_VERTS];
@@ -237,14 +283,13 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
         lv[v] = LightVtx{v3(0, 0, 0), 0.0f, 0.0f, 0.0f, 0.0f, -1, 0};
         GL[v] = 0.0f; RL[v] = 0.0f;
         if (v < Ll) {
-            const size_t k = (size_t)v * B + pid;
-            const float4 a = lp.P0[k], b = lp.P1[k], c = lp.P2[k], d = lp.P3[k];
+            const float4 a = La[v], b = Lb[v], c = Lcn[v], d = Ld[v];
             lv[v].o = v3(a);
             LNs[(3 * v + 0) * BLOCK + tid] = c.x; LNs[(3 * v + 1) * BLOCK + tid] = c.y; LNs[(3 * v + 2) * BLOCK + tid] = c.z;
             LCs[(3 * v + 0) * BLOCK + tid] = d.x; LCs[(3 * v + 1) * BLOCK + tid] = d.y; LCs[(3 * v + 2) * BLOCK + tid] = d.z;
             lv[v].c = a.w; lv[v].l = b.w; lv[v].tot = d.w;
             lv[v].cosv = __builtin_fabsf(dot(v3(b), v3(c)));
-            lv[v].tri = lp.tri[k];
+            lv[v].tri = Lt[v];
             lv[v].meta = __float_as_int(c.w);
             if (__float_as_int(mats[lv[v].meta & 0xFF].color_type.w) > 0) l_spec |= 1u << v;
         }
@@ -264,15 +309,12 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
     float contrib_weight_sum = 0.0f;
     float4 uni = make_float4(0, 0, 0, 0);
 
+    V3 prior_camera_color = v3(0, 0, 0);            // rays[t-2].color: the previous iteration's P3 (read once, not again)
     for (int t = 1; t < Lc + 1; t++) {
-        const size_t ck = (size_t)(t - 1) * B + pid;
-        const float4 cP0 = cp.P0[ck], cP1 = cp.P1[ck], cP2 = cp.P2[ck], cP3 = cp.P3[ck];
+        prior_camera_color = v3(cP3); load_camera_vertex(t);
         const int c_meta = __float_as_int(cP2.w);
-        const int c_tri = cp.tri[ck];
         const V3 c_o = v3(cP0), c_n = v3(cP2);
         const float c_cos = __builtin_fabsf(dot(v3(cP1), c_n));
-        V3 prior_camera_color = v3(0, 0, 0);
-        if (t >= 2) prior_camera_color = v3(cp.P3[ck - B]);
         // per-path camera tables, vertex v = t-1 (same statements as the light side above)
         {
             const int v = t - 1;
@@ -293,11 +335,6 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
             const V3 c = prior_camera_color / cP3.w;
             uni = make_float4(c.x, c.y, c.z, 1.0f);
         }
-        // all closest-hit results of this t in flight at once (entries of culled pairs are never used)
-        float2 hits[MAX_VERTS + 1];
-        hits[0] = make_float2(0.0f, 0.0f);
-#pragma unroll
-        for (int s = 1; s <= MAX_VERTS; s++) hits[s] = chit_load(chit, B, t, s, pid);
 #ifdef CL2_TEST_VARIANT
         if ((debug_flags & 2) && t >= 2) continue;      // timing dissection (test variant only): skip the t >= 2 / t == 1 pairs
         if ((debug_flags & 4) && t == 1) continue;
@@ -305,7 +342,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
 #define CL2_PAIR(S)                                                                                             \
         if ((S) <= Ll && t + (S) >= 2)                                                                          \
             resolve_pair<S>(t, B, pid, lv, GL, RL, l_spec, c_spec, spec7, c_o, c_n, cP0.w, cP1.w, cP3.w, c_cos, \
-                            c_tri, c_meta, prior_camera_color, GCs, RCs, LNs, LCs, mask, hits[S], tri_shade, mats, cam, \
+                            c_tri, c_meta, prior_camera_color, GCs, RCs, LNs, LCs, mask, hits[S], tri_shade, cam_tris, mats, cam, \
                             focal, cam_dir, total, contrib_weight_sum, light_image, splat_tab, debug_flags)
         CL2_PAIR(0); CL2_PAIR(1); CL2_PAIR(2); CL2_PAIR(3); CL2_PAIR(4); CL2_PAIR(5); CL2_PAIR(6);
 #undef CL2_PAIR

@@ -76,6 +76,7 @@ struct cl2_renderer {
     float4* d_wide = nullptr;
     int n_wide = 0;
     int n_fast = 0;                      // records of the pruned table (bvh.n_fast_nodes unless debug_flags bit 7 switches it off)
+    CamTris cam_tris{0, {0, 0, 0, 0}};   // the triangles with is_camera set, as kernel arguments of the resolve stage (n < 0: too many, look them up)
     int fast_flat = 0;                   // the pruned table is a plain list of leaves (bvh.fast_flat unless debug_flags bit 11 switches it off)
     float4* d_fast = nullptr;            // pruned record table of an LDS-resident tree (cl2_upload_scene); bvh.n_fast_nodes == 0: none
     WideView wide{};
@@ -515,7 +516,7 @@ int launch_resolve(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
         Timed t(r, ST_CONNECT_RESOLVE, st);
 #define CL2_RESOLVE(W, ML)                                                                                                       \
         hipLaunchKernelGGL((k_connect_resolve<W, ML>), dim3(grid_for(B)), dim3(BLOCK), 0, st, B, lp, cp, r->d_mats, r->n_mats, r->d_tri_shade,   \
-                           r->cam, r->d_cmask[cs], r->d_chit[cs], r->d_agg, r->d_light_image, r->d_uni, r->d_stats, r->debug_flags)
+                           r->cam_tris, r->cam, r->d_cmask[cs], r->d_chit[cs], r->d_agg, r->d_light_image, r->d_uni, r->d_stats, r->debug_flags)
         // 3 waves per SIMD: what 165 VGPRs and 52 KB of LDS tables per workgroup allow (2 / 4 measured slower: DESIGN 6.1).  Debug
         // bits 4-6 = 7: one wave per camera vertex (connect_resolve_wide.hpp: same results bit for bit, measured slower: 1.14 vs
         // 0.93 ms; a second implementation kept as a cross-check, built only with -DCL2_TEST_VARIANT = libclive2_amd_test.so)
@@ -937,6 +938,12 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
         }
     }
 
+    CamTris cam_tris{0, {0, 0, 0, 0}};
+    for (int t = 0; t < n_tris; t++) {
+        if (!tris[t].is_camera || cam_tris.n < 0) continue;
+        if (cam_tris.n == CAM_TRI_ARGS) cam_tris.n = -1;
+        else cam_tris.idx[cam_tris.n++] = t;
+    }
     for (int t = 0; t < n_tris; t++) {
         const TriRec& T = tris[t];
         // edge vectors: the same binary32 subtractions ray_triangle_intersect performs (trace.metal:118-119)
@@ -1022,6 +1029,7 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     }
     r->bvh.fast_flat = ((r->debug_flags >> 11) & 1) ? 0 : r->fast_flat;
     r->n_mats = n_mats; r->light_count = light_count; r->cam = cam;
+    r->cam_tris = cam_tris;
     r->n_top = n_top;
     r->scene_ok = true;
     r->paths_share = 0;                  // re-tune the stage shares for the new scene
