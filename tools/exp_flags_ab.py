@@ -1,4 +1,6 @@
-"""A/B of debug flags on the 1080p Cornell box, one process, alternating (ms per sample, pipelined + serial stages)."""
+"""Same-box A/B of debug-flag settings (include/clive2_amd.h) on the 1080p Cornell box:  python tools/exp_flags_ab.py 0 0x800 ...
+One process, three alternating rounds; ms per sample of the default (pipelined) organisation, the serial per-stage breakdown and a
+hash of the unidirectional accumulators (every setting must give the same one)."""
 import sys, time, os, hashlib
 sys.path.insert(0, os.getcwd())
 import bench

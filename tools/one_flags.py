@@ -1,3 +1,4 @@
+"""One scene, one debug-flag setting, a few serial samples (for rocprofv3 passes):  python3 tools/one_flags.py <flags> <scene> [samples]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
