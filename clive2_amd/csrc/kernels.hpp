@@ -861,13 +861,22 @@ __global__ __launch_bounds__(BLOCK, 6) void k_connect_setup(
     const V3 focal = cam3(cam.focal_point), cam_dir = cam3(cam.direction);
     const int lane = lane_id(), wave = threadIdx.x >> 6;
 
+    // The vertex loads are issued in batches -- the whole light subpath, then the camera subpath three vertices at a time -- and
+    // not one vertex per `if (v < L)`: inside its own conditional every vertex was a memory round trip of its own (13 per pixel
+    // in a kernel that does nothing but wait for memory; now 4).  A vertex slot is fetched when SOME lane of the wave has it.
+    const size_t vB = (size_t)B;
+    float4 la[MAX_VERTS], lc[MAX_VERTS];
+#pragma unroll
+    for (int s = 0; s < MAX_VERTS; s++) {
+        if (__builtin_amdgcn_ballot_w64(s < Ll) != 0ull) { la[s] = lp.P0[s * vB + pid]; lc[s] = lp.P2[s * vB + pid]; }
+        else la[s] = lc[s] = make_float4(0, 0, 0, 0);
+    }
     ConnVtx lv[MAX_VERTS];
     unsigned l_spec = 0;
 #pragma unroll
     for (int s = 0; s < MAX_VERTS; s++) {
         if (s < Ll) {
-            const float4 a = lp.P0[(size_t)s * B + pid], c = lp.P2[(size_t)s * B + pid];
-            lv[s] = ConnVtx{v3(a), v3(c), __float_as_int(c.w)};
+            lv[s] = ConnVtx{v3(la[s]), v3(lc[s]), __float_as_int(lc[s].w)};
             if (s_mtype[lv[s].meta & 0xFF] > 0) l_spec |= 1u << s;
         } else lv[s] = ConnVtx{v3(0, 0, 0), v3(0, 0, 0), 0};
     }
@@ -875,20 +884,29 @@ __global__ __launch_bounds__(BLOCK, 6) void k_connect_setup(
     unsigned long long mine = 0;
     unsigned wave_total = 0;
 #pragma unroll
-    for (int t = 1; t <= MAX_VERTS; t++) {
-        ConnVtx cv{v3(0, 0, 0), v3(0, 0, 0), 0};
-        bool c_specular = false;
-        if (t <= Lc) {
-            const float4 a = cp.P0[(size_t)(t - 1) * B + pid], c = cp.P2[(size_t)(t - 1) * B + pid];
-            cv = ConnVtx{v3(a), v3(c), __float_as_int(c.w)};
-            c_specular = s_mtype[cv.meta & 0xFF] > 0;
+    for (int tb = 0; tb < MAX_VERTS; tb += 3) {
+        float4 ca[3], cc[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (__builtin_amdgcn_ballot_w64(tb + k < Lc) != 0ull) { ca[k] = cp.P0[(tb + k) * vB + pid]; cc[k] = cp.P2[(tb + k) * vB + pid]; }
+            else ca[k] = cc[k] = make_float4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (int s = 1; s <= MAX_VERTS; s++) {
-            V3 dir;
-            const bool pred = (t <= Lc) && (s <= Ll) && conn_ray(t, lv[s - 1], cv, (l_spec >> (s - 1)) & 1u, c_specular, focal, cam_dir, dir);
-            if (pred) mine |= 1ull << conn_slot(t, s);
-            wave_total += __popcll(__ballot(pred));
+        for (int k = 0; k < 3; k++) {
+            const int t = tb + k + 1;
+            ConnVtx cv{v3(0, 0, 0), v3(0, 0, 0), 0};
+            bool c_specular = false;
+            if (t <= Lc) {
+                cv = ConnVtx{v3(ca[k]), v3(cc[k]), __float_as_int(cc[k].w)};
+                c_specular = s_mtype[cv.meta & 0xFF] > 0;
+            }
+#pragma unroll
+            for (int s = 1; s <= MAX_VERTS; s++) {
+                V3 dir;
+                const bool pred = (t <= Lc) && (s <= Ll) && conn_ray(t, lv[s - 1], cv, (l_spec >> (s - 1)) & 1u, c_specular, focal, cam_dir, dir);
+                if (pred) mine |= 1ull << conn_slot(t, s);
+                wave_total += __popcll(__ballot(pred));
+            }
         }
     }
     if (lane == 0) s_wave_total[wave] = wave_total;
