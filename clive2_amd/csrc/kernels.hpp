@@ -864,11 +864,13 @@ __global__ __launch_bounds__(BLOCK, 6) void k_connect_setup(
     // The vertex loads are issued in batches -- the whole light subpath, then the camera subpath three vertices at a time -- and
     // not one vertex per `if (v < L)`: inside its own conditional every vertex was a memory round trip of its own (13 per pixel
     // in a kernel that does nothing but wait for memory; now 4).  A vertex slot is fetched when SOME lane of the wave has it.
-    const size_t vB = (size_t)B;
+    // The fetch of a slot is decided per WAVE, so lanes behind the end of the frame (the last workgroup of a frame that is not a
+    // multiple of 256 pixels) take part in it: they read pixel 0's records (slot 5 of pixel >= B would lie behind the buffer).
+    const size_t vB = (size_t)B, lpid = valid ? (size_t)pid : 0;
     float4 la[MAX_VERTS], lc[MAX_VERTS];
 #pragma unroll
     for (int s = 0; s < MAX_VERTS; s++) {
-        if (__builtin_amdgcn_ballot_w64(s < Ll) != 0ull) { la[s] = lp.P0[s * vB + pid]; lc[s] = lp.P2[s * vB + pid]; }
+        if (__builtin_amdgcn_ballot_w64(s < Ll) != 0ull) { la[s] = lp.P0[s * vB + lpid]; lc[s] = lp.P2[s * vB + lpid]; }
         else la[s] = lc[s] = make_float4(0, 0, 0, 0);
     }
     ConnVtx lv[MAX_VERTS];
@@ -888,7 +890,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_connect_setup(
         float4 ca[3], cc[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            if (__builtin_amdgcn_ballot_w64(tb + k < Lc) != 0ull) { ca[k] = cp.P0[(tb + k) * vB + pid]; cc[k] = cp.P2[(tb + k) * vB + pid]; }
+            if (__builtin_amdgcn_ballot_w64(tb + k < Lc) != 0ull) { ca[k] = cp.P0[(tb + k) * vB + lpid]; cc[k] = cp.P2[(tb + k) * vB + lpid]; }
             else ca[k] = cc[k] = make_float4(0, 0, 0, 0);
         }
 #pragma unroll
