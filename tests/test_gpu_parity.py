@@ -241,6 +241,36 @@ def test_oversized_leaves_and_big_material_table(mode, oracle_mod):
     assert c["tri_tests"] > 0 and c["box_tests"] >= c["counted_rays"]
 
 
+def test_more_camera_triangles_than_kernel_arguments(oracle_mod):
+    """The resolve kernel takes the is_camera triangles as kernel arguments (up to 4: the reference's scenes have the 2 of
+    the film quad) and falls back to the look-up in the shading records beyond.  Six flagged triangles (the film quad and
+    two walls -- a scene no preset makes, but a legal Triangle[]): subpaths, aggregators, light splats and ray tally as the
+    oracle's; and a scene with exactly 4."""
+    import copy
+    import clive2_amd as c2
+    from clive2_amd.renderer import Renderer, make_seeds
+    for extra in (4, 2):
+        scene = copy.deepcopy(c2.create_scene_from_preset("empty", 48, 32))
+        tri = scene.triangles
+        walls = [i for i in range(len(tri)) if not tri["is_camera"][i] and not tri["is_light"][i]][:extra]
+        tri["is_camera"][walls] = 1
+        assert int(tri["is_camera"].sum()) == 2 + extra
+        seeds = make_seeds(48 * 32)
+        r, o = Renderer(scene, seeds=seeds), oracle_mod.OracleRenderer(scene, seeds=seeds)
+        _run_to_paths(r, o)
+        for which, ref in ((LIGHT, o.out_light_paths), (CAMERA, o.out_camera_paths)):
+            assert r.export_paths(which).tobytes() == ref.tobytes()
+        _run_rest(r, o)
+        agg = r.export_aggregators()
+        assert agg["total_contribution"].tobytes() == o.weight_aggregators["total_contribution"].tobytes()
+        assert agg["weights"].tobytes() == o.weight_aggregators["weights"].tobytes()
+        img, wts, _, _ = r.read_accumulators()
+        assert np.allclose(img, o.summed_image, rtol=5e-5, atol=1e-8)              # the t = 1 splats (float atomics)
+        assert np.allclose(wts, o.summed_sample_weights, rtol=5e-5, atol=1e-8)
+        assert r.counters()["rays"] == o.rays_traced
+        r.close()
+
+
 def test_all_material_types_bit_exact(oracle_mod):
     """Material types the shipped table never reaches: type 1 with alpha 0 (smooth
     dielectric through the general GGX route), type 2 (Fresnel-weighted reflect / diffuse), type >= 3
