@@ -241,6 +241,29 @@ def test_oversized_leaves_and_big_material_table(mode, oracle_mod):
     assert c["tri_tests"] > 0 and c["box_tests"] >= c["counted_rays"]
 
 
+@pytest.mark.parametrize("size", [(1, 1), (1, 7), (257, 1), (3, 2)])
+def test_tiny_and_ragged_frames(size, oracle_mod):
+    """Frames of one pixel, one column, one row of 257 pixels (one full workgroup + 1): a single partial workgroup, wave-level
+    batches with most lanes behind the end of the frame (the out-of-bounds read the round-3 fuzz found lived there).  Three
+    samples through the pipeline: seeds, last sample's subpaths, image and ray tally as the oracle's; the device tone map runs."""
+    import clive2_amd as c2
+    from clive2_amd.renderer import Renderer, make_seeds
+    w, h = size
+    scene = c2.create_scene_from_preset("empty", w, h)
+    seeds = make_seeds(w * h)
+    r, o = Renderer(scene, seeds=seeds), oracle_mod.OracleRenderer(scene, seeds=seeds)
+    r.run_samples(3)
+    for _ in range(3):
+        o.run_sample()
+    assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
+    assert r.export_paths(LIGHT).tobytes() == o.out_light_paths.tobytes()
+    assert r.export_paths(CAMERA).tobytes() == o.out_camera_paths.tobytes()
+    assert np.allclose(r.read_accumulators()[0], o.summed_image, rtol=5e-5, atol=1e-8)
+    assert r.counters()["rays"] == o.rays_traced
+    assert r.tone_mapped("image").shape == (h, w, 3)
+    r.close()
+
+
 def test_more_camera_triangles_than_kernel_arguments(oracle_mod):
     """The resolve kernel takes the is_camera triangles as kernel arguments (up to 4: the reference's scenes have the 2 of
     the film quad) and falls back to the look-up in the shading records beyond.  Six flagged triangles (the film quad and
