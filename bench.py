@@ -422,6 +422,11 @@ def main():
     # cl2_comm_allreduce_f64, the all-reduce inside the timed region -- on a one-rank communicator.
     W, H = args.width, args.height
     with_comm = world > 1 or os.environ.get("CLIVE2_BENCH_FORCE_COMM") == "1"
+    # stdout carries ONE JSON line.  Libraries write there too (RCCL prints a version banner on stdout when a communicator comes
+    # up), so for the length of the run the file descriptor points at stderr; it is put back for the line itself.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     strong = args.total_spp > 0
     if strong:
         from clive2_amd.distributed import samples_for_rank
@@ -466,7 +471,10 @@ def main():
                                 stage_ms_per_step_serial=m["stages"])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_width, args.cpu_height, args.cpu_samples)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+    os.close(saved_stdout)
 
 
 if __name__ == "__main__":

@@ -5,8 +5,10 @@ all-reduce inside the library (`cl2_comm_init_rank` / `cl2_reduce_accumulators`,
 this module holds the host side of it: the rank environment, the sample partition, and the hand-over
 of RCCL's unique id from rank 0 to the other ranks of the node through a file.  torch is not needed.
 """
+import contextlib
 import os
 import stat
+import sys
 import tempfile
 import time
 
@@ -93,6 +95,22 @@ def finish_exchange(rank, path=None):
             pass
 
 
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """RCCL prints a version banner on STDOUT when a communicator comes up (seen with 2.27.7: five lines on rank 0).  A rank's
+    stdout belongs to the caller -- bench.py prints ONE JSON line there -- so the library's chatter goes to stderr: the file
+    descriptor itself is redirected for the duration of the call (the banner is written by C code, not through sys.stdout)."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def join_communicator(renderer, rank, world_size, path=None, timeout=180.0):
     """The whole bootstrap for one rank: id from rank 0, `comm_init` (collective), clean-up."""
     # All ranks of this job are processes of ONE node (the id travels through a local file), so RCCL's own
@@ -101,9 +119,11 @@ def join_communicator(renderer, rank, world_size, path=None, timeout=180.0):
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC between the ranks' processes on this pool
     n = renderer._L.cl2_comm_unique_id_bytes()
-    uid = exchange_unique_id(rank, world_size, renderer.comm_unique_id, n, path=path, timeout=timeout)
+    with _stdout_to_stderr():
+        uid = exchange_unique_id(rank, world_size, renderer.comm_unique_id, n, path=path, timeout=timeout)
     try:
-        renderer.comm_init(rank, world_size, uid)
+        with _stdout_to_stderr():
+            renderer.comm_init(rank, world_size, uid)
     except Exception as e:
         # RCCL's "invalid usage" at this point is almost always two ranks on one device (one GPU per rank is required)
         raise type(e)(f"{e}  [rank {rank} of {world_size} on device {renderer.device}: every rank needs a GPU of its own -- "
