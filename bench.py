@@ -287,6 +287,14 @@ def dry_child(rank, local_rank, world):
     if rank == int(os.environ.get("CLIVE2_BENCH_DRY_FAIL_RANK", "-1")):
         print(f"[rank {rank}] dry-spawn: failing on request", file=sys.stderr)
         sys.exit(3)
+    hang_dir = os.environ.get("CLIVE2_BENCH_DRY_HANG_DIR")
+    if hang_dir:
+        # a rank that never finishes (stands for one blocked in a collective): the clean-up tests end the PARENT and look for us
+        with open(os.path.join(hang_dir, f"rank{rank}.pid.tmp"), "w") as f:
+            f.write(str(os.getpid()))
+        os.replace(os.path.join(hang_dir, f"rank{rank}.pid.tmp"), os.path.join(hang_dir, f"rank{rank}.pid"))
+        time.sleep(300.0)
+        sys.exit(4)
     path = rendezvous_path()
     uid = exchange_unique_id(rank, world, lambda: os.urandom(128), 128, timeout=60.0)
     me = {"rank": rank, "local_rank": local_rank, "world": world, "pid": os.getpid(), "ppid": os.getppid(),
@@ -311,12 +319,30 @@ def dry_child(rank, local_rank, world):
                       "ids_equal": len({v["id_sha"] for v in seen.values()}) == 1 and len(seen) == world}), flush=True)
 
 
+def _die_with_parent():
+    """preexec_fn of the rank processes: the kernel sends SIGTERM to the child when its parent dies -- however it dies,
+    SIGKILL included, which no handler in the parent can see (prctl PR_SET_PDEATHSIG; Linux).  A rank that holds a GPU must
+    not outlive the job that started it."""
+    import ctypes
+    import signal
+    try:
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)      # PR_SET_PDEATHSIG = 1
+    except (OSError, AttributeError):
+        pass
+
+
 def spawn_ranks(n, argv, timeout):
     """The parent of `python bench.py --gpus N` (N > 1, no launcher environment).  It makes NO GPU / HIP call and never
     loads the library: it starts N fresh processes of this script (one per GPU) with RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* and ONE shared CLIVE2_RENDEZVOUS_FILE (a fresh name: no stale file can exist), waits, relays rank 0's
-    stdout (the JSON line) and returns the first non-zero exit code (after ending the other ranks), else 0."""
+    stdout (the JSON line) and returns the first non-zero exit code (after ending the other ranks), else 0.
+
+    No exit path leaves a rank behind: the wait loop sits in try/finally, so an exception, Ctrl-C or a SIGTERM
+    from the driver's time limit (turned into rc 128 + signal by the handlers below) ends every live child -- terminate,
+    wait, then kill -- and removes the rendezvous file; and every child asks the kernel for a SIGTERM of its own when this
+    process dies without running any of that (SIGKILL, out-of-memory kill): _die_with_parent."""
     import secrets
+    import signal
     import socket
     import subprocess
     import tempfile
@@ -325,50 +351,72 @@ def spawn_ranks(n, argv, timeout):
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     rdv = os.path.join(tempfile.gettempdir(), f"clive2_bench_id_{os.getuid()}_{os.getpid()}_{secrets.token_hex(8)}")
-    procs = []
-    for rank in range(n):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CLIVE2_RENDEZVOUS_FILE=rdv,
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        # rank 0's stdout is the job's stdout (one JSON line); the other ranks' goes to stderr
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr, stdin=subprocess.DEVNULL))
-    chunks = []
-    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
-    reader.start()
-    rc, deadline = 0, time.monotonic() + timeout
-    live = set(range(n))
-    while live and rc == 0:
-        for k in sorted(live):
-            code = procs[k].poll()
-            if code is None:
-                continue
-            live.discard(k)
-            if code != 0:
-                print(f"bench.py: rank {k} exited with {code}; ending the other ranks", file=sys.stderr)
-                rc = code if code > 0 else 1
+    procs, chunks, reader = [], [], None
+    stop = {"signal": 0}
+
+    def on_signal(signum, _frame):
+        stop["signal"] = signum
+
+    previous = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
+    rc = 0
+    try:
+        for rank in range(n):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CLIVE2_RENDEZVOUS_FILE=rdv,
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            # rank 0's stdout is the job's stdout (one JSON line); the other ranks' goes to stderr
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, preexec_fn=_die_with_parent,
+                                          stdout=subprocess.PIPE if rank == 0 else sys.stderr, stdin=subprocess.DEVNULL))
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        deadline = time.monotonic() + timeout
+        live = set(range(n))
+        while live and rc == 0:
+            if stop["signal"]:
+                print(f"bench.py: signal {stop['signal']}; ending the ranks", file=sys.stderr)
+                rc = 128 + stop["signal"]
                 break
-        if rc == 0 and live and time.monotonic() > deadline:
-            print(f"bench.py: ranks {sorted(live)} still running after {timeout:.0f} s; ending them", file=sys.stderr)
-            rc = 124
-        if rc == 0 and live:
-            time.sleep(0.05)
-    if rc != 0:
-        for k in live:                      # exactly the processes started above, by pid
-            procs[k].terminate()
-        t_kill = time.monotonic() + 10.0
-        for k in live:
+            for k in sorted(live):
+                code = procs[k].poll()
+                if code is None:
+                    continue
+                live.discard(k)
+                if code != 0:
+                    print(f"bench.py: rank {k} exited with {code}; ending the other ranks", file=sys.stderr)
+                    rc = code if code > 0 else 1
+                    break
+            if rc == 0 and live and time.monotonic() > deadline:
+                print(f"bench.py: ranks {sorted(live)} still running after {timeout:.0f} s; ending them", file=sys.stderr)
+                rc = 124
+            if rc == 0 and live:
+                time.sleep(0.05)
+    except BaseException:
+        rc = rc or 1
+        raise
+    finally:
+        # exactly the processes started above, by pid: terminate, give them ten seconds, kill what is left
+        alive = [p for p in procs if p.poll() is None]
+        for p in alive:
             try:
-                procs[k].wait(timeout=max(0.1, t_kill - time.monotonic()))
+                p.terminate()
+            except OSError:
+                pass
+        t_kill = time.monotonic() + 10.0
+        for p in alive:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
             except subprocess.TimeoutExpired:
-                procs[k].kill()
-                procs[k].wait()
-    reader.join(timeout=10.0)
-    for leftover in glob.glob(rdv + "*"):
-        try:
-            os.unlink(leftover)
-        except OSError:
-            pass
+                p.kill()
+                p.wait()
+        if reader is not None:
+            reader.join(timeout=10.0)
+        for leftover in glob.glob(rdv + "*"):
+            try:
+                os.unlink(leftover)
+            except OSError:
+                pass
+        for sg, h in previous.items():
+            signal.signal(sg, h)
     if rc == 0:
         sys.stdout.write(b"".join(chunks).decode(errors="replace"))
         sys.stdout.flush()

@@ -14,15 +14,20 @@ import glob
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libclive2_amd.so")
 # the test variant additionally carries the second implementation of the resolve stage
-# (csrc/connect_resolve_wide.hpp, -DCL2_TEST_VARIANT): a cross-check for tests, not shipped code
+# (tests/connect_resolve_wide.hpp, -DCL2_TEST_VARIANT): a cross-check for tests, not shipped code
 TEST_LIB_PATH = os.path.join(_PKG, "libclive2_amd_test.so")
 _MAIN_SOURCES = [os.path.join(_PKG, "csrc", "renderer_api.hip"), os.path.join(_PKG, "csrc", "bvh_builder_gpu.hip")]
 _HEADER = os.path.join(os.path.dirname(_PKG), "include", "clive2_amd.h")
 
 
-def _sources():
-    """Everything the translation unit includes: every file under csrc/ plus the public header."""
-    return sorted(glob.glob(os.path.join(_PKG, "csrc", "*.hip")) + glob.glob(os.path.join(_PKG, "csrc", "*.hpp"))) + [_HEADER]
+_TEST_ONLY_SOURCES = [os.path.join(os.path.dirname(_PKG), "tests", "connect_resolve_wide.hpp")]
+
+
+def _sources(variant=None):
+    """Everything the translation unit includes: every file under csrc/ plus the public header (the test variant also
+    includes the cross-check resolve kernel that lives under tests/)."""
+    own = sorted(glob.glob(os.path.join(_PKG, "csrc", "*.hip")) + glob.glob(os.path.join(_PKG, "csrc", "*.hpp"))) + [_HEADER]
+    return own + (_TEST_ONLY_SOURCES if variant == "test" else [])
 
 # -ffp-contract=off / no fast-math: every float op of the kernels rounds once, in source order.
 # -fno-slp-vectorize: packed fp32 VALU ops (v_pk_mul/add_f32) issue at half the rate of scalar ones on
@@ -81,7 +86,7 @@ def needs_build(variant=None):
     if not os.path.exists(path):
         return True
     t = os.path.getmtime(path)
-    return any(os.path.getmtime(s) > t for s in _sources())
+    return any(os.path.getmtime(s) > t for s in _sources(variant))
 
 
 def build(force=False, verbose=False, variant=None):

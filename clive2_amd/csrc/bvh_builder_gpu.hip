@@ -355,7 +355,10 @@ extern "C" int cl2_build_bvh_gpu(int device_ordinal, const double* tri_min, cons
                 unsigned long long tot = 0;
                 LB_TRY(hipMemcpy(&tot, d_tot, sizeof tot, hipMemcpyDeviceToHost));
                 const int keep = (int)(tot & 0xFFFFFFFFull), merged = (int)(tot >> 32);
-                if (merged < 1 || keep != m - merged) return bad(CL2_E_HIP, "internal error: a PLOC round merged nothing");
+                if (keep != m - merged) return bad(CL2_E_HIP, "internal error: a PLOC round lost clusters");
+                // nothing merged: no cluster found a neighbour (every union area +inf or NaN -- huge or NaN coordinates).  Not an
+                // error of the input: the radix tree below needs no areas
+                if (merged < 1) break;
                 next += merged; m = keep; rounds++;
                 std::swap(d_cid_a, d_cid_b);
             }

@@ -228,7 +228,11 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
     }
     const MaterialDev* __restrict__ mats = MATS_LDS ? s_mats : mats_g;     // compile-time choice: plain LDS reads, not generic ones
     const int pid = blockIdx.x * BLOCK + tid;
-    if (pid >= B) return;                              // no block-wide barrier below: LDS rows are private per thread
+    // The `pid >= B` contract (clamped_pid, kernels.hpp): the light-subpath fetches below are decided per WAVE, so every lane
+    // that reaches them must own a pixel.  This return guarantees it -- it must stay in FRONT of the first such fetch, and no
+    // block-wide barrier may follow it (the LDS rows are private per thread, the splat exchange is per wave).
+    if (pid >= B) return;
+    __builtin_assume(pid < B);
     const int Lc = cp.len[pid], Ll = lp.len[pid];
     const unsigned long long mask = cmask[pid];
     const V3 focal = cam3(cam.focal_point), cam_dir = cam3(cam.direction);

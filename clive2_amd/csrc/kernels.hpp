@@ -843,6 +843,13 @@ __device__ __forceinline__ bool conn_ray(int t, const ConnVtx& lv, const ConnVtx
     return true;
 }
 
+// The `pid >= B` contract of kernels whose loads are decided per WAVE (`if (ballot(slot < len)) load slot`): the lanes behind
+// the end of a frame that is not a multiple of 256 pixels take part in such a load although they own no pixel, and slot v of
+// pixel >= B lies behind the allocation for v = MAX_VERTS - 1 (the out-of-bounds READ of round 3, found by the fuzz).  Such a
+// kernel either indexes every wave-decided load with clamped_pid() -- the lanes without a pixel read pixel 0's records and
+// never use them -- or returns for pid >= B before the first of them (k_connect_resolve).
+__device__ __forceinline__ size_t clamped_pid(bool valid, int pid) { return valid ? (size_t)pid : (size_t)0; }
+
 // Enumerate strategy pairs per pixel, emit connection rays into a compacted queue of 4-byte tags
 // {slot, pixel}.  Tags are ordered wave-by-wave, slot-major inside a wave, so consecutive queue
 // entries are the same (t,s) strategy of neighbouring pixels: the vertex gathers of
@@ -866,7 +873,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_connect_setup(
     // in a kernel that does nothing but wait for memory; now 4).  A vertex slot is fetched when SOME lane of the wave has it.
     // The fetch of a slot is decided per WAVE, so lanes behind the end of the frame (the last workgroup of a frame that is not a
     // multiple of 256 pixels) take part in it: they read pixel 0's records (slot 5 of pixel >= B would lie behind the buffer).
-    const size_t vB = (size_t)B, lpid = valid ? (size_t)pid : 0;
+    const size_t vB = (size_t)B, lpid = clamped_pid(valid, pid);
     float4 la[MAX_VERTS], lc[MAX_VERTS];
 #pragma unroll
     for (int s = 0; s < MAX_VERTS; s++) {
@@ -981,7 +988,7 @@ constexpr int AGG_ROWS = 13;
 }  // namespace cl2
 #include "connect_resolve.hpp"
 #ifdef CL2_TEST_VARIANT
-#include "connect_resolve_wide.hpp"
+#include "../../tests/connect_resolve_wide.hpp"      // test code: a second implementation of the resolve stage (cross-check only)
 #endif
 namespace cl2 {
 

@@ -14,6 +14,7 @@
 #include <limits>
 #include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/clive2_amd.h"
@@ -518,7 +519,7 @@ int launch_resolve(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
         hipLaunchKernelGGL((k_connect_resolve<W, ML>), dim3(grid_for(B)), dim3(BLOCK), 0, st, B, lp, cp, r->d_mats, r->n_mats, r->d_tri_shade,   \
                            r->cam_tris, r->cam, r->d_cmask[cs], r->d_chit[cs], r->d_agg, r->d_light_image, r->d_uni, r->d_stats, r->debug_flags)
         // 3 waves per SIMD: what 165 VGPRs and 52 KB of LDS tables per workgroup allow (2 / 4 measured slower: DESIGN 6.1).  Debug
-        // bits 4-6 = 7: one wave per camera vertex (connect_resolve_wide.hpp: same results bit for bit, measured slower: 1.14 vs
+        // bits 4-6 = 7: one wave per camera vertex (tests/connect_resolve_wide.hpp: same results bit for bit, measured slower: 1.14 vs
         // 0.93 ms; a second implementation kept as a cross-check, built only with -DCL2_TEST_VARIANT = libclive2_amd_test.so)
         const int occ = (r->debug_flags >> 4) & 7;
         if (occ != 0 && occ != 7) return fail(r, CL2_E_INVALID, "debug bits 4-6 must be 0 or 7");
@@ -691,10 +692,29 @@ int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_render
 void cl2_destroy(cl2_renderer* r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
+    // A handle whose collective failed or timed out was torn down with ncclCommAbort; whether that retires the collective's
+    // kernel on r->stream is RCCL's business (unverified on hardware: RCCL has never run here with more than one rank), and
+    // an unbounded hipStreamSynchronize on that stream would turn "exit non-zero" into "hang in destroy" (ADVICE r3).  Such a
+    // handle polls its streams for a few seconds and then LEAKS its device resources (hipFree would wait as well): the
+    // process is on its way out with an error.
+    const bool poisoned = r->comm_poisoned;
     if (r->comm) (void)cl2_comm_destroy(r);
-    if (r->stream) (void)hipStreamSynchronize(r->stream);
-    if (r->stream_conn) (void)hipStreamSynchronize(r->stream_conn);
-    if (r->stream_res) (void)hipStreamSynchronize(r->stream_res);
+    auto settle = [&](hipStream_t s) -> bool {
+        if (!s) return true;
+        if (!poisoned) { (void)hipStreamSynchronize(s); return true; }
+        const auto until = std::chrono::steady_clock::now() + std::chrono::seconds(5);
+        for (;;) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e != hipErrorNotReady) return true;          // drained, or in an error state: nothing left to wait for
+            if (std::chrono::steady_clock::now() > until) return false;
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+    };
+    const bool s0 = settle(r->stream), s1 = settle(r->stream_conn), s2 = settle(r->stream_res);   // every stream gets its poll
+    if (!(s0 && s1 && s2)) {
+        std::fprintf(stderr, "clive2_amd: cl2_destroy: a stream did not drain after the communicator was aborted; leaking the handle\n");
+        return;
+    }
     for (auto e : r->ev_paths) if (e) (void)hipEventDestroy(e);
     for (auto e : r->ev_conn) if (e) (void)hipEventDestroy(e);
     for (auto e : r->ev_res) if (e) (void)hipEventDestroy(e);
@@ -1204,8 +1224,8 @@ int cl2_run_samples(cl2_renderer* r, int n) {
 }
 
 /* Makes the measured choices of the launch organisation NOW instead of inside the first (long) cl2_run_samples
- * call: the levels-per-launch probe of a small scene (1 sample) and the stage-share tuner of a large one (30
- * samples).  The samples are real ones -- they advance the seeds and add to the accumulators exactly as the same
+ * call: the levels-per-launch probe of a small scene (1 sample) and the stage-share tuner of a large one (42
+ * samples: TUNE_TOTAL).  The samples are real ones -- they advance the seeds and add to the accumulators exactly as the same
  * number of run_sample iterations would -- and *samples_rendered says how many there were.  A benchmark calls
  * this in its warm-up so that no timing experiment runs inside its clock. */
 int cl2_tune(cl2_renderer* r, int* samples_rendered) {

@@ -61,9 +61,15 @@ class Renderer:
         self.set_seeds(make_seeds(self.batch_size) if seeds is None else seeds)
 
     # ---- plumbing ----
+    _FATAL = (-2, -5)                    # CL2_E_HIP, CL2_E_COMM (include/clive2_amd.h): the device or the communicator is gone
+
     def _check(self, rc, what):
         if rc != 0:
-            self._failed = True          # close() then aborts the communicator instead of waiting for peers
+            # close() aborts the communicator of a FAILED handle instead of waiting for peers.  A refused argument or a call out
+            # of sequence (CL2_E_INVALID, CL2_E_STATE, CL2_E_NOMEM) leaves device and communicator healthy: a caller that catches
+            # it and carries on must not tear the communicator down under peers that are fine.
+            if rc in self._FATAL:
+                self._failed = True
             msg = self._L.cl2_last_error(self._h)
             raise RendererError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
 
@@ -185,6 +191,11 @@ class Renderer:
         Same arithmetic and dtypes as the host path; the float64 log-luminance sum is added in another order, so a byte
         can differ from `.image` where 255*x/(x+w) lies within ~1e-13 of an integer."""
         w = self._PICTURES[which]
+        # the device arithmetic restates what numpy >= 2 (NEP 50 promotion) makes of camera.py:73-82: the float32 picture times
+        # the exposure stays float32 and is widened by the division by the float64 Lw.  numpy 1.x keeps `result` in float32
+        # (value-based casting), and the host path then differs from this one by far more than one count (ADVICE r3).
+        if int(np.__version__.split(".")[0]) < 2:
+            raise RendererError("tone_mapped() reproduces the reference's tone map under numpy >= 2 (NEP 50) only; use .image")
         s = C.c_double(0.0)
         self._check(self._L.cl2_tone_log_sum(self._h, w, C.byref(s)), "cl2_tone_log_sum")
         log_avg = np.exp(np.float64(s.value) / (self.pixel_height * self.pixel_width))       # Lw, with numpy's exp

@@ -235,6 +235,59 @@ def test_bench_spawn_propagates_a_rank_failure():
     assert p.returncode == 3 and p.stdout.strip() == ""
 
 
+@pytest.mark.parametrize("how", ["SIGTERM", "SIGINT", "SIGKILL"])
+def test_bench_spawn_leaves_no_rank_behind_when_the_parent_is_ended(how, tmp_path):
+    """a parent that is interrupted or killed must not leave rank processes holding their GPUs.
+    The ranks here never finish (CLIVE2_BENCH_DRY_HANG_DIR: they stand for ranks blocked in a collective).  SIGTERM /
+    SIGINT: the parent's handlers fall into its clean-up (terminate, wait, kill), it exits 128 + signal and removes the
+    rendezvous file.  SIGKILL: no handler runs; every child asked the kernel for a SIGTERM on its parent's death
+    (PR_SET_PDEATHSIG) and is gone all the same."""
+    import signal
+    import subprocess
+    import tempfile
+    import time
+    before = set(os.listdir(tempfile.gettempdir()))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "CLIVE2_RENDEZVOUS_FILE")}
+    env["CLIVE2_BENCH_DRY_HANG_DIR"] = str(tmp_path)
+    parent = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-spawn"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        deadline = time.monotonic() + 60.0
+        while len(list(tmp_path.glob("rank*.pid"))) < 3 and time.monotonic() < deadline:
+            time.sleep(0.05)
+        pids = [int(f.read_text()) for f in sorted(tmp_path.glob("rank*.pid"))]
+        assert len(pids) == 3 and parent.poll() is None
+
+        def alive(pid):
+            try:
+                with open(f"/proc/{pid}/stat") as f:
+                    return f.read().rsplit(")", 1)[1].split()[0] != "Z"       # a zombie has exited
+            except OSError:
+                return False
+        assert all(alive(p) for p in pids)
+        parent.send_signal(getattr(signal, how))
+        rc = parent.wait(timeout=30)
+        t_gone = time.monotonic() + 15.0
+        while any(alive(p) for p in pids) and time.monotonic() < t_gone:
+            time.sleep(0.05)
+        assert not any(alive(p) for p in pids), "rank processes survived their parent"
+        if how == "SIGKILL":
+            assert rc == -signal.SIGKILL
+        else:
+            assert rc == 128 + int(getattr(signal, how))
+            assert parent.stdout.read().strip() == b""
+            left = [f for f in set(os.listdir(tempfile.gettempdir())) - before if f.startswith("clive2_bench_id_")]
+            assert not left
+    finally:
+        if parent.poll() is None:
+            parent.kill()
+        for f in tmp_path.glob("rank*.pid"):
+            try:
+                os.kill(int(f.read_text()), signal.SIGKILL)
+            except (OSError, ValueError):
+                pass
+
+
 def test_bench_single_process_paths_are_unchanged():
     """--gpus 1 does not spawn; under a launcher environment (WORLD_SIZE set) the script is a rank, whatever --gpus says;
     the invalid-render debug bits are refused."""

@@ -206,3 +206,23 @@ def test_ploc_builder_survives_coincident_triangles():
         b = boxes[:nb.value]
         leaves = b[b["right"] != 0]
         assert (leaves["right"] - leaves["left"]).sum() == n and (leaves["right"] - leaves["left"]).max() <= 8
+
+
+def test_ploc_falls_back_when_no_union_area_is_finite():
+    """boxes so large that every union area overflows float32 (+inf) give no cluster a nearest neighbour, so a
+    PLOC round merges nothing.  That is not an error of the input: the radix tree (which needs no areas) is built."""
+    import ctypes as C
+    from clive2_amd import _native, struct_types as st
+    L = _native.lib()
+    L.cl2_build_bvh_gpu.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                    C.POINTER(C.c_int64), C.c_void_p]
+    rng = np.random.RandomState(11)
+    n = 500
+    lo = rng.rand(n, 3) * 1e25; hi = lo + rng.rand(n, 3) * 1e24
+    boxes, perm, nb = np.zeros(2 * n, st.Box), np.full(n, -1, np.int64), C.c_int64(0)
+    rc = L.cl2_build_bvh_gpu(0, _native.ptr(lo), _native.ptr(hi), n, 8, _native.ptr(boxes), len(boxes), C.byref(nb), _native.ptr(perm))
+    assert rc == 0, L.cl2_last_error(None)
+    assert np.array_equal(np.sort(perm), np.arange(n))
+    b = boxes[:nb.value]
+    leaves = b[b["right"] != 0]
+    assert (leaves["right"] - leaves["left"]).sum() == n and (leaves["right"] - leaves["left"]).max() <= 8

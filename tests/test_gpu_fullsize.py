@@ -357,3 +357,101 @@ def test_config5_real_size_1080p_and_4k_properties(interior_real):
     r.close()
     r4, c4 = _full_frame_properties(interior_real.with_resolution(3840, 2160), 1)
     assert 50 < c4["box_tests"] / c4["counted_rays"] < 65
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Round 4: the mesh configs against the ORACLE at their full frames.  Until now the oracle
+# followed C3 / C4 / C5 only at 160x90 / 128x72 / 96x54, and the full frames -- which run another organisation (two-
+# stage sample pipeline above 2^19 pixels, 512-ray chunks, stage shares, 21-23-bit pixel ids in the tags) -- were
+# checked by properties and HIP-vs-HIP comparisons.  Here every stage output of a full-frame sample is compared with
+# the CPU restatement of trace.metal:144-176, :381-532, :620-869 on the same seeds.
+def _same_bytes(a, b):
+    a = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
+    b = np.ascontiguousarray(b).reshape(-1).view(np.uint8)
+    return a.size == b.size and bool(np.array_equal(a, b))
+
+
+def _compare_with_oracle(r, o, paths=True):
+    """Everything one sample leaves behind: RNG state, both Path[] buffers and the filter aggregators bytewise, ray
+    tally, accumulated images (the light-image splat is the one place with a tolerance: float atomics)."""
+    assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
+    if paths:
+        assert _same_bytes(r.export_paths(LIGHT), o.out_light_paths)
+        assert _same_bytes(r.export_paths(CAMERA), o.out_camera_paths)
+    agg = r.export_aggregators()
+    for f in ("total_contribution", "weights", "contrib_weight_sum"):
+        assert _same_bytes(agg[f], o.weight_aggregators[f]), f
+    assert r.counters()["rays"] == o.rays_traced
+    img, wts, cnt, uni = r.read_accumulators()
+    np.testing.assert_allclose(img, o.summed_image, rtol=5e-5, atol=1e-8)
+    np.testing.assert_allclose(wts, o.summed_sample_weights, rtol=5e-5, atol=1e-8)
+    assert _same_bytes(uni, o.unidirectional_image_buffer)
+    assert np.array_equal(cnt, o.summed_sample_counts)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rad_r = np.nan_to_num(img / wts, neginf=0, posinf=0)
+    l2 = np.sqrt(((rad_r - o.radiance) ** 2).sum(axis=2))
+    assert l2.max() < 1e-3                                   # the north star's per-pixel bound
+
+
+def _full_frame_vs_oracle(scene, oracle_mod, more=3, forced_shares=(), paths=True):
+    """One sample through run_samples(1) in the default organisation (serial order), a counting pass for the node /
+    triangle tallies, then run_samples(more): the sample pipeline with its rotating buffer sets and stage shares."""
+    from clive2_amd.renderer import Renderer, make_seeds
+    B = scene.pixel_width * scene.pixel_height
+    seeds = make_seeds(B)
+    r, o = Renderer(scene, seeds=seeds), oracle_mod.OracleRenderer(scene, seeds=seeds)
+    org = r.organisation()
+    assert not org["tree_in_lds"] and org["persistent_connections"] and org["wide_connections"]
+    r.run_samples(1)
+    o.run_sample()
+    _compare_with_oracle(r, o, paths)
+    box, tri = int(o.counters["box_tests"][0]), int(o.counters["tri_tests"][0])
+    rc = Renderer(scene, seeds=seeds)
+    rc.set_counting(True)                                    # the tallies are defined by the binary walk: its own pass
+    rc.run_samples(1)
+    c = rc.counters()
+    rc.close()
+    assert c["rays"] == o.rays_traced and c["counted_rays"] == c["rays"]
+    assert c["box_tests"] == box and c["tri_tests"] == tri
+    done = 1
+    if more:
+        assert r.organisation()["pipeline_stages"] >= 1 or B <= (1 << 19)
+        r.run_samples(more)
+        for _ in range(more):
+            o.run_sample()
+        done += more
+        _compare_with_oracle(r, o, paths)
+    for share in forced_shares:                              # the organisations the share tuner chooses between
+        r.set_debug_flags(share << 8)
+        r.run_samples(2)
+        o.run_sample(); o.run_sample()
+        done += 2
+        _compare_with_oracle(r, o, paths=False)
+    assert r.samples == done == o.samples
+    r.close()
+    return c
+
+
+def test_config3_1080p_vs_oracle(oracle_mod):
+    """BASELINE config 3 (Cornell box + 5,120-triangle rough-glass sphere) at 1920x1080: 1 + 3 samples, then two samples
+    each with the subpath stage held to 3 and to 5 eighths of the wave slots."""
+    c = _full_frame_vs_oracle(_glass(4, 1920, 1080), oracle_mod, more=3, forced_shares=(3, 5))
+    assert 8 < c["box_tests"] / c["counted_rays"] < 16       # N_node 11.4 (DESIGN 6)
+
+
+def test_config4_1080p_vs_oracle(blob_real, oracle_mod):
+    """BASELINE config 4 stand-in (81,936 triangles) at 1920x1080: 1 + 3 samples."""
+    c = _full_frame_vs_oracle(blob_real.with_resolution(1920, 1080), oracle_mod, more=3)
+    assert 14 < c["box_tests"] / c["counted_rays"] < 19
+
+
+def test_config5_1080p_vs_oracle(interior_real, oracle_mod):
+    """BASELINE config 5 stand-in (1,003,536 triangles, 155 MB of tree) at 1920x1080: 1 + 3 samples."""
+    c = _full_frame_vs_oracle(interior_real.with_resolution(1920, 1080), oracle_mod, more=3)
+    assert 50 < c["box_tests"] / c["counted_rays"] < 65
+
+
+def test_config5_4k_vs_oracle(interior_real, oracle_mod):
+    """... and at the config's own 3840x2160 (8.3 M pixels: 23-bit pixel ids in the connection tags, per-level subpath
+    launches in the serial order): one sample, Path[] included (2 x 8.6 GB per side)."""
+    _full_frame_vs_oracle(interior_real.with_resolution(3840, 2160), oracle_mod, more=0)

@@ -264,6 +264,43 @@ def test_tiny_and_ragged_frames(size, oracle_mod):
     r.close()
 
 
+@pytest.mark.parametrize("size", [(91, 60), (257, 1)])
+def test_ragged_frames_with_short_subpaths(size, oracle_mod):
+    """The same frames over an OPEN scene with a rough-glass ball (emitter, floor, back wall only: most subpaths end
+    after a bounce or two, so the wave-level `some lane has vertex slot v` ballots of k_connect_setup / k_connect_resolve are
+    sparse and differ from wave to wave) at 91x60 = 21 x 256 + 84 pixels -- the frame of the round-3 fault -- and at one row
+    of 257.  The contract those kernels keep for the lanes behind the frame's end is clamped_pid() (csrc/kernels.hpp)."""
+    import clive2_amd as c2
+    from clive2_amd.load import get_materials
+    from clive2_amd.meshes import icosphere
+    from clive2_amd.renderer import Renderer, make_seeds
+    w, h = size
+    mats = get_materials()
+    mats["alpha"][5] = 0.1
+    from clive2_amd.load import triangles_for_box
+    keep = [t for t in triangles_for_box() if t.emitter or t.n[1] > 0.5 or t.n[2] > 0.5]          # emitter, floor, back wall
+    scene = c2.create_scene(w, h, np.array([0, 1.5, 6]), np.array([0, 0, -1]), room=keep, materials=mats,
+                            file_specs=[dict(mesh=icosphere(3, radius=1.5), material=5, offset=np.array([0.5, 0.0, -1.0]))])
+    assert len(scene.triangles) > 512                                      # not LDS-resident: mode 0 = the persistent organisation
+    seeds = make_seeds(w * h)
+    for mode in (0, 1):                                     # persistent organisation (the tree is not LDS-resident) and one ray per lane
+        r, o = Renderer(scene, seeds=seeds), oracle_mod.OracleRenderer(scene, seeds=seeds)
+        r.set_traversal_mode(mode)
+        r.run_samples(3)
+        for _ in range(3):
+            o.run_sample()
+        lens = o.out_camera_paths["length"]
+        assert (lens <= 2).mean() > 0.2 and (lens >= 4).any()          # short subpaths dominate, long ones exist
+        assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
+        assert r.export_paths(LIGHT).tobytes() == o.out_light_paths.tobytes()
+        assert r.export_paths(CAMERA).tobytes() == o.out_camera_paths.tobytes()
+        agg = r.export_aggregators()
+        assert agg["total_contribution"].tobytes() == o.weight_aggregators["total_contribution"].tobytes()
+        assert np.allclose(r.read_accumulators()[0], o.summed_image, rtol=5e-5, atol=1e-8)
+        assert r.counters()["rays"] == o.rays_traced
+        r.close()
+
+
 def test_more_camera_triangles_than_kernel_arguments(oracle_mod):
     """The resolve kernel takes the is_camera triangles as kernel arguments (up to 4: the reference's scenes have the 2 of
     the film quad) and falls back to the look-up in the shading records beyond.  Six flagged triangles (the film quad and
@@ -722,7 +759,7 @@ def test_scene_near_the_lds_caps_keeps_its_residency(oracle_mod):
 @pytest.mark.parametrize("scene_name", ["cornell_small", "glass_scene"])
 def test_wide_resolve_kernel_agrees(scene_name, request, oracle_mod):
     """The second implementation of the resolve stage (one wave per camera vertex, running total relayed
-    between the waves; csrc/connect_resolve_wide.hpp) reproduces the oracle's aggregators, unidirectional
+    between the waves; tests/connect_resolve_wide.hpp) reproduces the oracle's aggregators, unidirectional
     estimate and image exactly like the default one-thread-per-pixel kernel."""
     from clive2_amd.renderer import Renderer, RendererError, make_seeds
     scene = request.getfixturevalue(scene_name)

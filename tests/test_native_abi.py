@@ -83,8 +83,10 @@ def test_editing_any_kernel_source_triggers_a_rebuild(monkeypatch, tmp_path):
     assert not _native.needs_build()
     srcs = _native._sources()
     names = {os.path.basename(s) for s in srcs}
-    assert {"renderer_api.hip", "kernels.hpp", "connect_resolve.hpp", "connect_resolve_wide.hpp", "bvh_traverse.hpp",
+    assert {"renderer_api.hip", "kernels.hpp", "connect_resolve.hpp", "bvh_traverse.hpp",
             "comm_rccl.hpp", "clive2_amd.h"} <= names
+    assert "connect_resolve_wide.hpp" not in names                  # test code lives under tests/ ...
+    assert "connect_resolve_wide.hpp" in {os.path.basename(s) for s in _native._sources("test")}   # ... and only the test variant sees it
     newest = max(os.path.getmtime(s) for s in srcs)
     fake = tmp_path / "lib.so"
     fake.write_bytes(b"")
@@ -226,3 +228,25 @@ def test_invalid_render_switches_are_not_in_the_shipped_library(cornell_small):
     t = Renderer(cornell_small, seeds=seeds, variant="test")
     t.set_debug_flags(2)                                              # the test variant carries the dissection switches
     t.close()
+
+
+def test_only_device_and_communicator_errors_poison_the_handle():
+    """a refused argument (CL2_E_INVALID / CL2_E_STATE / CL2_E_NOMEM) leaves device and communicator healthy,
+    so close() must destroy the communicator cleanly; CL2_E_HIP / CL2_E_COMM mark the handle failed (close() aborts)."""
+    from clive2_amd.renderer import Renderer, RendererError
+
+    class FakeLib:
+        def cl2_last_error(self, h):
+            return b"reason"
+    r = Renderer.__new__(Renderer)
+    r._L, r._h = FakeLib(), None
+    for rc in (-1, -3, -4):
+        with pytest.raises(RendererError):
+            r._check(rc, "call")
+        assert not getattr(r, "_failed", False)
+    for rc in (-2, -5):
+        r._failed = False
+        with pytest.raises(RendererError):
+            r._check(rc, "call")
+        assert r._failed
+    r._h = None                                  # nothing for __del__ to close
