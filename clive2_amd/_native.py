@@ -55,7 +55,8 @@ class Counters(C.Structure):
 class Organisation(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("tree_in_lds", "persistent_subpaths", "persistent_connections", "two_tris_per_step",
                                          "n_records", "n_lds_records", "n_top_renumbered", "lds_triangles",
-                                         "levels_per_launch", "paths_share", "pipeline_stages", "wide_connections", "wide_nodes", "pruned_records")] + [("tree_bytes", C.c_int64)]
+                                         "levels_per_launch", "paths_share", "pipeline_stages", "wide_connections", "wide_nodes", "pruned_records")] + \
+               [("tree_bytes", C.c_int64), ("sample_streams", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -72,6 +73,7 @@ EXPORTS = [
     "cl2_reset_counters", "cl2_selftest_exact_math", "cl2_export_rays", "cl2_export_paths", "cl2_export_aggregators",
     "cl2_export_sample_images", "cl2_probe_traverse", "cl2_probe_math", "cl2_probe_bounce",
     "cl2_tune", "cl2_set_subpath_gather", "cl2_comm_abort", "cl2_tone_log_sum", "cl2_tone_map",
+    "cl2_set_sample_streams", "cl2_get_sample_streams", "cl2_set_export_stream",
 ]
 
 
@@ -128,6 +130,9 @@ def lib(variant=None):
         L.cl2_comm_allreduce_f64.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]
         L.cl2_tune.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.cl2_set_subpath_gather.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.cl2_set_sample_streams.argtypes = [C.c_void_p, C.c_int]
+        L.cl2_get_sample_streams.argtypes = [C.c_void_p]
+        L.cl2_set_export_stream.argtypes = [C.c_void_p, C.c_int]
         L.cl2_tone_log_sum.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
         L.cl2_tone_map.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_size_t]
         for name in ("cl2_reduce_accumulators", "cl2_comm_destroy", "cl2_comm_abort", "cl2_synchronize"):

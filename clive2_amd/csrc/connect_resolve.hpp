@@ -165,8 +165,12 @@ __device__ __forceinline__ void resolve_pair(
 #else
         const bool splat_on = true;
 #endif
-        if (light_pixel_idx >= 0 && light_pixel_idx < B && splat_on) {
+        const int frame_pixels = cam.pixel_width * cam.pixel_height;
+        if (light_pixel_idx >= 0 && light_pixel_idx < frame_pixels && splat_on) {
             const V3 c = ((w * shade) * prior_color) * mcol;
+            // the light image of THIS entry's sample stream (computed here, in the rare branch, not carried through the kernel:
+            // it runs at 162 of 168 VGPRs)
+            const int splat_idx = (pid - pid % frame_pixels) + light_pixel_idx;
             // Splat {c.xyz, w} into light_image[pixel] (float4).  The lanes that reach this point
             // exchange their 4 values through a per-wave LDS table so that four CONSECUTIVE lanes
             // add the four components of one pixel: each atomic wave-instruction then carries whole
@@ -174,7 +178,7 @@ __device__ __forceinline__ void resolve_pair(
             float* tab = splat_tab + (threadIdx.x >> 6) * (5 * 64);
             const unsigned long long here = __ballot(true);
             const int n_here = __popcll(here), k = __popcll(here & ((1ull << (threadIdx.x & 63)) - 1ull));
-            tab[0 * 64 + k] = __int_as_float(light_pixel_idx);
+            tab[0 * 64 + k] = __int_as_float(splat_idx);
             tab[1 * 64 + k] = c.x; tab[2 * 64 + k] = c.y; tab[3 * 64 + k] = c.z; tab[4 * 64 + k] = w;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
         __syncthreads();                               // before any thread leaves
     }
     const MaterialDev* __restrict__ mats = MATS_LDS ? s_mats : mats_g;     // compile-time choice: plain LDS reads, not generic ones
-    const int pid = blockIdx.x * BLOCK + tid;
+    const int pid = blockIdx.x * BLOCK + tid;           // entry: pixel pid % (W*H) of sample stream pid / (W*H) (kernels.hpp, header)
     // The `pid >= B` contract (clamped_pid, kernels.hpp): the light-subpath fetches below are decided per WAVE, so every lane
     // that reaches them must own a pixel.  This return guarantees it -- it must stay in FRONT of the first such fetch, and no
     // block-wide barrier may follow it (the LDS rows are private per thread, the splat exchange is per wave).
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
 
     // ---- reconstruction-filter weights, trace.metal:827-862.  A zero-length camera path is the
     // reference's zero-filled Path: pixel 0, film point (0,0,0). ----
-    const int pixel_idx = (Lc > 0) ? pid : 0;
+    const int pixel_idx = (Lc > 0) ? pid % (cam.pixel_width * cam.pixel_height) : 0;
     V3 film = v3(0, 0, 0);
     if (Lc > 0) film = v3(cp.P0[pid]);
     const float ppw = cam.phys_width / cam.pixel_width, pph = cam.phys_height / cam.pixel_height;

@@ -24,6 +24,12 @@
 //   P0 = {origin.xyz, c_importance}  P1 = {direction.xyz, l_importance}
 //   P2 = {normal.xyz, meta}          P3 = {color.xyz, tot_importance}     tri = triangle index
 //   meta = material | hit_light<<8 | hit_camera<<9
+// Sample streams (cl2_set_sample_streams): a handle may carry K independent samples of the frame per pass.  Every per-pixel
+// array then has K x W x H entries, entry k*W*H + p being pixel p of stream k -- exactly what K Renderers with K seed buffers
+// (renderer.py:86-87; the ranks of the sample split) would hold -- and every launch covers all of them: `B` below is that
+// entry count (the array stride), the frame's own pixel count is camera.pixel_width x pixel_height.  Only four places
+// look at a pixel's POSITION and take `entry % (W*H)`: the camera-ray generator, the reconstruction-filter weights, the
+// filter gather of K6 and the light-image splat; the accumulators are per pixel (K6 adds the streams in order).
 // Every arithmetic statement follows the cited reference lines in the same operation order
 // (IEEE binary32, -ffp-contract=off), so per-stage results can be compared exactly with a CPU
 // evaluation of the same statements.
@@ -142,7 +148,8 @@ __global__ __launch_bounds__(BLOCK) void k_gen_light_rays(
 __device__ __forceinline__ void gen_camera_ray(int id, const CameraRec& c, uint32_t& seed0, uint32_t& seed1, const PathBufs& pb) {
     const float x_offset = xorshift_random(seed0);
     const float y_offset = xorshift_random(seed1);
-    const int pixel_x = id % c.pixel_width, pixel_y = id / c.pixel_width;
+    const int pix = id % (c.pixel_width * c.pixel_height);          // the pixel of entry `id` (sample streams: see the header)
+    const int pixel_x = pix % c.pixel_width, pixel_y = pix / c.pixel_width;
     const float xn = (pixel_x + x_offset - 0.5f * c.pixel_width) / (float)c.pixel_width;
     const float yn = (pixel_y + y_offset - 0.5f * c.pixel_height) / (float)c.pixel_height;
     const V3 xv = (xn * cam3(c.dx)) * c.phys_width;
@@ -998,13 +1005,15 @@ __global__ __launch_bounds__(BLOCK) void k_finalize(int B, int W, int H, const f
                                                     float4* __restrict__ finalized, float* __restrict__ sample_w) {
     const int id = blockIdx.x * BLOCK + threadIdx.x;
     if (id >= B) return;
+    const int pix = id % (W * H);                                     // entry -> pixel; its neighbours are entries of the same stream
+    const size_t base = (size_t)(id - pix);
     V3 total = v3(0, 0, 0);
     float wsum = 0.0f;
     for (int i = -1; i < 2; i++) {
         for (int j = -1; j < 2; j++) {
-            const int sx = (id % W) + i, sy = (id / W) + j;
+            const int sx = (pix % W) + i, sy = (pix / W) + j;
             if (sx < 0 || sx >= W || sy < 0 || sy >= H) continue;
-            const size_t k = (size_t)sy * W + sx;
+            const size_t k = base + (size_t)sy * W + sx;
             const float weight = agg[(size_t)((1 - i) * 3 + (1 - j)) * B + k];
             total = total + weight * v3(agg[(size_t)9 * B + k], agg[(size_t)10 * B + k], agg[(size_t)11 * B + k]);
             wsum += weight * agg[(size_t)12 * B + k];
@@ -1022,54 +1031,78 @@ __device__ __forceinline__ float scrub(float x) {   // np.nan_to_num(x, posinf=0
 // Accumulators stay on the device: acc rows = summed_image rgb (0..2), summed_sample_weights (3),
 // unidirectional rgb (4..6), summed_sample_counts as float (7).  The light image is zeroed for the
 // next sample.
-__global__ __launch_bounds__(BLOCK) void k_accumulate(int B, const float4* __restrict__ finalized,
+// `FB` = pixels of the frame, `streams` = samples per pixel in this pass (entries s*FB + id): added in stream order, each
+// exactly as one process_images call adds one sample.
+__global__ __launch_bounds__(BLOCK) void k_accumulate(int FB, int streams, const float4* __restrict__ finalized,
                                                       const float* __restrict__ sample_w, float4* __restrict__ light_image,
                                                       const float4* __restrict__ uni, float* __restrict__ acc) {
     const int id = blockIdx.x * BLOCK + threadIdx.x;
-    if (id >= B) return;
-    const float4 f = finalized[id], l = light_image[id], u = uni[id];
-    acc[(size_t)0 * B + id] += scrub(l.x + f.x);
-    acc[(size_t)1 * B + id] += scrub(l.y + f.y);
-    acc[(size_t)2 * B + id] += scrub(l.z + f.z);
-    acc[(size_t)3 * B + id] += sample_w[id] + l.w;      // K8's `sum_weights[id] += weight_sum`, :963
-    acc[(size_t)4 * B + id] += scrub(u.x);
-    acc[(size_t)5 * B + id] += scrub(u.y);
-    acc[(size_t)6 * B + id] += scrub(u.z);
-    acc[(size_t)7 * B + id] += 1.0f;
-    light_image[id] = make_float4(0, 0, 0, 0);
+    if (id >= FB) return;
+    float a[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) a[c] = acc[(size_t)c * FB + id];
+#pragma unroll 1
+    for (int s = 0; s < streams; s++) {
+        const size_t e = (size_t)s * FB + id;
+        const float4 f = finalized[e], l = light_image[e], u = uni[e];
+        a[0] += scrub(l.x + f.x);
+        a[1] += scrub(l.y + f.y);
+        a[2] += scrub(l.z + f.z);
+        a[3] += sample_w[e] + l.w;                      // K8's `sum_weights[id] += weight_sum`, :963
+        a[4] += scrub(u.x);
+        a[5] += scrub(u.y);
+        a[6] += scrub(u.z);
+        a[7] += 1.0f;
+        light_image[e] = make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++) acc[(size_t)c * FB + id] = a[c];
 }
 
 // K6 + process_images in one launch for cl2_run_samples: the filtered sample goes straight from registers into the
 // accumulators (the per-sample images finalized / sample_weights are not written: they are what the stage calls
 // cl2_finalize_samples / cl2_process_images exchange, 36 B per pixel and a launch boundary per sample).
 // Same statements in the same order as k_finalize followed by k_accumulate.
+// `B` = entries (streams x W x H, the stride of the aggregator rows); one thread per PIXEL adds its streams in order.
 __global__ __launch_bounds__(BLOCK) void k_finalize_accumulate(int B, int W, int H, const float* __restrict__ agg,
                                                                float4* __restrict__ light_image, const float4* __restrict__ uni,
                                                                float* __restrict__ acc) {
     const int id = blockIdx.x * BLOCK + threadIdx.x;
-    if (id >= B) return;
-    V3 total = v3(0, 0, 0);
-    float wsum = 0.0f;
-    for (int i = -1; i < 2; i++) {
-        for (int j = -1; j < 2; j++) {
-            const int sx = (id % W) + i, sy = (id / W) + j;
-            if (sx < 0 || sx >= W || sy < 0 || sy >= H) continue;
-            const size_t k = (size_t)sy * W + sx;
-            const float weight = agg[(size_t)((1 - i) * 3 + (1 - j)) * B + k];
-            total = total + weight * v3(agg[(size_t)9 * B + k], agg[(size_t)10 * B + k], agg[(size_t)11 * B + k]);
-            wsum += weight * agg[(size_t)12 * B + k];
+    const int FB = W * H;
+    if (id >= FB) return;
+    float a[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) a[c] = acc[(size_t)c * FB + id];
+#pragma unroll 1
+    for (size_t base = 0; base < (size_t)B; base += (size_t)FB) {
+        V3 total = v3(0, 0, 0);
+        float wsum = 0.0f;
+        // one row of three neighbours in flight at a time: unrolled all the way the nine gathers take 136 VGPRs
+#pragma unroll 1
+        for (int i = -1; i < 2; i++) {
+#pragma unroll
+            for (int j = -1; j < 2; j++) {
+                const int sx = (id % W) + i, sy = (id / W) + j;
+                if (sx < 0 || sx >= W || sy < 0 || sy >= H) continue;
+                const size_t k = base + (size_t)sy * W + sx;
+                const float weight = agg[(size_t)((1 - i) * 3 + (1 - j)) * B + k];
+                total = total + weight * v3(agg[(size_t)9 * B + k], agg[(size_t)10 * B + k], agg[(size_t)11 * B + k]);
+                wsum += weight * agg[(size_t)12 * B + k];
+            }
         }
+        const float4 l = light_image[base + id], u = uni[base + id];
+        a[0] += scrub(l.x + total.x);
+        a[1] += scrub(l.y + total.y);
+        a[2] += scrub(l.z + total.z);
+        a[3] += wsum + l.w;
+        a[4] += scrub(u.x);
+        a[5] += scrub(u.y);
+        a[6] += scrub(u.z);
+        a[7] += 1.0f;
+        light_image[base + id] = make_float4(0, 0, 0, 0);
     }
-    const float4 l = light_image[id], u = uni[id];
-    acc[(size_t)0 * B + id] += scrub(l.x + total.x);
-    acc[(size_t)1 * B + id] += scrub(l.y + total.y);
-    acc[(size_t)2 * B + id] += scrub(l.z + total.z);
-    acc[(size_t)3 * B + id] += wsum + l.w;
-    acc[(size_t)4 * B + id] += scrub(u.x);
-    acc[(size_t)5 * B + id] += scrub(u.y);
-    acc[(size_t)6 * B + id] += scrub(u.z);
-    acc[(size_t)7 * B + id] += 1.0f;
-    light_image[id] = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < 8; c++) acc[(size_t)c * FB + id] = a[c];
 }
 
 // ---------------------------------------------------------------- exactness self-test
@@ -1159,23 +1192,24 @@ __device__ __forceinline__ void fill_ray(RayRec& r, const PathBufs& pb, size_t k
     r.pad[0] = r.pad[1] = r.pad[2] = 0;
 }
 
-__global__ void k_export_rays(int B, PathBufs pb, int from_camera, RayRec* out) {
+// exports of ONE sample stream: `n` = pixels of the frame, `off` = first entry of the stream, `B` = entries (row stride)
+__global__ void k_export_rays(int n, int off, PathBufs pb, int from_camera, RayRec* out) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= B) return;
+    if (id >= n) return;
     RayRec r;
-    fill_ray(r, pb, id, from_camera, from_camera ? id : 0);
+    fill_ray(r, pb, (size_t)off + id, from_camera, from_camera ? id : 0);
     out[id] = r;
 }
 
 // Path record = 8 RayRec + length + from_camera + pad[2] (1040 B).  Slots >= length are zero.
-__global__ void k_export_paths(int B, PathBufs pb, int from_camera, unsigned char* out) {
+__global__ void k_export_paths(int n, int off, int B, PathBufs pb, int from_camera, unsigned char* out) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= B) return;
+    if (id >= n) return;
     unsigned char* rec = out + (size_t)id * 1040;
-    const int len = pb.len[id];
+    const int len = pb.len[off + id];
     for (int v = 0; v < 8; v++) {
         RayRec r;
-        if (v < len) fill_ray(r, pb, (size_t)v * B + id, v == 0 ? from_camera : 0, (v == 0 && from_camera) ? id : 0);
+        if (v < len) fill_ray(r, pb, (size_t)v * B + off + id, v == 0 ? from_camera : 0, (v == 0 && from_camera) ? id : 0);
         else memset(&r, 0, sizeof r);
         *reinterpret_cast<RayRec*>(rec + 128 * v) = r;
     }
@@ -1184,14 +1218,15 @@ __global__ void k_export_paths(int B, PathBufs pb, int from_camera, unsigned cha
 }
 
 // WeightAggregator records at the reference's 128-byte host stride (renderer.py:71).
-__global__ void k_export_aggregators(int B, const float* __restrict__ agg, float* out) {
+__global__ void k_export_aggregators(int n, int off, int B, const float* __restrict__ agg, float* out) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= B) return;
+    if (id >= n) return;
     float* rec = out + (size_t)id * 32;
+    const size_t e = (size_t)off + id;
     for (int i = 0; i < 32; i++) rec[i] = 0.0f;
-    for (int r = 0; r < 9; r++) rec[r] = agg[(size_t)r * B + id];
-    rec[12] = agg[(size_t)9 * B + id]; rec[13] = agg[(size_t)10 * B + id]; rec[14] = agg[(size_t)11 * B + id];
-    rec[16] = agg[(size_t)12 * B + id];
+    for (int r = 0; r < 9; r++) rec[r] = agg[(size_t)r * B + e];
+    rec[12] = agg[(size_t)9 * B + e]; rec[13] = agg[(size_t)10 * B + e]; rec[14] = agg[(size_t)11 * B + e];
+    rec[16] = agg[(size_t)12 * B + e];
 }
 
 }  // namespace cl2

@@ -47,7 +47,11 @@ template <typename T> struct DevBuf {
 }  // namespace
 
 struct cl2_renderer {
-    int device = 0, W = 0, H = 0, B = 0;
+    // B = ENTRIES of every per-pixel array = streams x FB (cl2_set_sample_streams; kernels.hpp header): what every launch covers
+    // and every stride is; FB = W x H, the pixels of the frame: accumulators, tone map, the multi-GPU reduce, exports of one stream
+    int device = 0, W = 0, H = 0, B = 0, FB = 0;
+    int streams = 1;                     // independent samples of the frame per pass (one seed buffer each, as K Renderers would hold)
+    int export_stream = 0;               // the stream the debug exports / sample-image calls address
     hipStream_t stream = nullptr;        // subpath phase (and everything else when not pipelining)
     hipStream_t stream_conn = nullptr;   // sample pipeline: connection set-up + connection rays
     hipStream_t stream_res = nullptr;    // sample pipeline: resolve + K6 + accumulation
@@ -523,6 +527,7 @@ int launch_resolve(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
         // 0.93 ms; a second implementation kept as a cross-check, built only with -DCL2_TEST_VARIANT = libclive2_amd_test.so)
         const int occ = (r->debug_flags >> 4) & 7;
         if (occ != 0 && occ != 7) return fail(r, CL2_E_INVALID, "debug bits 4-6 must be 0 or 7");
+        if (occ == 7 && r->streams != 1) return fail(r, CL2_E_INVALID, "the cross-check resolve kernel handles one sample stream");
 #ifdef CL2_TEST_VARIANT
         if (occ == 7)
             hipLaunchKernelGGL(k_connect_resolve_wide, dim3((B + RW_PIX - 1) / RW_PIX), dim3(RW_BLOCK), 0, st, B, lp, cp, r->d_mats,
@@ -550,7 +555,7 @@ int launch_finalize(cl2_renderer* r, hipStream_t st) {
 
 int launch_accumulate(cl2_renderer* r, hipStream_t st) {
     Timed t(r, ST_ACCUMULATE, st);
-    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(r->B)), dim3(BLOCK), 0, st, r->B, r->d_finalized, r->d_sample_w,
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(r->FB)), dim3(BLOCK), 0, st, r->FB, r->streams, r->d_finalized, r->d_sample_w,
                        r->d_light_image, r->d_uni, r->d_acc);
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;
@@ -558,7 +563,7 @@ int launch_accumulate(cl2_renderer* r, hipStream_t st) {
 
 int launch_finalize_accumulate(cl2_renderer* r, hipStream_t st) {
     Timed t(r, ST_FINALIZE, st);
-    hipLaunchKernelGGL(k_finalize_accumulate, dim3(grid_for(r->B)), dim3(BLOCK), 0, st, r->B, r->W, r->H, r->d_agg, r->d_light_image,
+    hipLaunchKernelGGL(k_finalize_accumulate, dim3(grid_for(r->FB)), dim3(BLOCK), 0, st, r->B, r->W, r->H, r->d_agg, r->d_light_image,
                        r->d_uni, r->d_acc);
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;
@@ -572,6 +577,66 @@ int need_scene(cl2_renderer* r) {
     return CL2_OK;
 }
 
+// Everything that has one entry per (sample stream, pixel): allocated for r->B = r->streams x r->FB entries and initialised
+// as cl2_create always did (seeds 1, zero lengths / images / masks).  cl2_set_sample_streams frees and re-allocates it.
+void free_pixel_state(cl2_renderer* r) {
+    dev_free(r, r->d_seeds);
+    for (int q = 0; q < 3; q++)
+        for (int k = 0; k < 2; k++) {
+            PathBufs& pb = r->sets[q][k];
+            dev_free(r, pb.P0); dev_free(r, pb.P1); dev_free(r, pb.P2); dev_free(r, pb.P3);
+            dev_free(r, pb.tri); dev_free(r, pb.len); dev_free(r, pb.carry);
+        }
+    dev_free(r, r->d_hit); dev_free(r, r->d_hit_cam0); dev_free(r, r->d_queue); dev_free(r, r->d_ctag);
+    for (int q = 0; q < 2; q++) { dev_free(r, r->d_chit[q]); dev_free(r, r->d_cmask[q]); }
+    dev_free(r, r->d_agg); dev_free(r, r->d_light_image); dev_free(r, r->d_finalized); dev_free(r, r->d_uni);
+    dev_free(r, r->d_sample_w); dev_free(r, r->d_block_stats);
+}
+
+int alloc_pixel_state(cl2_renderer* r) {
+    const size_t B = (size_t)r->B;
+    int rc = CL2_OK;
+#define A(ptr, count) if (rc == CL2_OK) rc = dev_alloc(r, &(ptr), (count))
+    A(r->d_seeds, B);
+    for (int q = 0; q < 3; q++) {
+        for (int k = 0; k < 2; k++) {
+            PathBufs& pb = r->sets[q][k];
+            A(pb.P0, MAX_VERTS * B); A(pb.P1, MAX_VERTS * B); A(pb.P2, MAX_VERTS * B); A(pb.P3, MAX_VERTS * B);
+            A(pb.tri, MAX_VERTS * B); A(pb.len, B); A(pb.carry, B);
+        }
+    }
+    A(r->d_hit, B);
+    A(r->d_hit_cam0, B);
+    A(r->d_queue, MAX_VERTS * B);
+    A(r->d_ctag, (size_t)CONN_SLOTS * B);
+    for (int q = 0; q < 2; q++) { A(r->d_chit[q], (size_t)CONN_SLOTS * B); A(r->d_cmask[q], B); }
+    A(r->d_agg, (size_t)AGG_ROWS * B);
+    A(r->d_light_image, B); A(r->d_finalized, B); A(r->d_uni, B);
+    A(r->d_sample_w, B);
+    A(r->d_block_stats, (size_t)grid_for(B) * 4);
+#undef A
+    if (rc != CL2_OK) return rc;
+    unsigned qc[9] = {(unsigned)r->B, 0, 0, 0, 0, 0, 0, 0, 2u * (unsigned)r->B};      // [8]: ray count of the merged level-0 launch
+    bool ok = hipMemcpy(r->d_qcount, qc, sizeof qc, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemset(r->d_light_image, 0, B * sizeof(float4)) == hipSuccess;
+    ok = ok && hipMemset(r->d_finalized, 0, B * sizeof(float4)) == hipSuccess;
+    ok = ok && hipMemset(r->d_uni, 0, B * sizeof(float4)) == hipSuccess;
+    ok = ok && hipMemset(r->d_sample_w, 0, B * sizeof(float)) == hipSuccess;
+    ok = ok && hipMemset(r->d_agg, 0, (size_t)AGG_ROWS * B * sizeof(float)) == hipSuccess;
+    ok = ok && hipMemset(r->d_block_stats, 0, (size_t)grid_for(B) * 4 * sizeof(unsigned long long)) == hipSuccess;
+    for (int q = 0; q < 2 && ok; q++) ok = hipMemset(r->d_cmask[q], 0, B * sizeof(unsigned long long)) == hipSuccess;
+    for (int q = 0; q < 3 && ok; q++)
+        for (int k = 0; k < 2 && ok; k++) ok = hipMemset(r->sets[q][k].len, 0, B * sizeof(int)) == hipSuccess;
+    // default seeds: 1 everywhere (xorshift's only forbidden state is 0); callers set real seeds
+    if (ok) {
+        std::vector<uint32_t> ones(2 * B, 1u);
+        ok = hipMemcpy(r->d_seeds, ones.data(), 2 * B * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) return fail(r, CL2_E_HIP, "device buffer initialisation failed");
+    r->cur = 0;
+    return CL2_OK;
+}
+
 #define STAGE_PROLOGUE(r)                 \
     do {                                  \
         int rc_ = need_scene(r);          \
@@ -582,7 +647,7 @@ int need_scene(cl2_renderer* r) {
 
 extern "C" {
 
-int cl2_abi_version(void) { return 2; }
+int cl2_abi_version(void) { return 3; }
 
 int cl2_build_bvh(const double* tri_min, const double* tri_max, int64_t n_triangles, int max_members, int max_depth,
                   void* out_boxes, int64_t box_capacity, int64_t* n_boxes_out, int64_t* out_perm) {
@@ -613,7 +678,7 @@ const char* cl2_last_error(const cl2_renderer* r) { return r ? r->err.c_str() : 
 int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_renderer** out) {
     if (!out) { g_create_error = "out is NULL"; return CL2_E_INVALID; }
     *out = nullptr;
-    if (pixel_width < 1 || pixel_height < 1 || (long long)pixel_width * pixel_height >= (1ll << TAG_PID_BITS)) {
+    if (pixel_width < 1 || pixel_height < 1 || (long long)pixel_width * pixel_height >= (1ll << TAG_PID_BITS)) {     // also checked per stream count
         g_create_error = "frame size out of range (need 1 <= W*H < 2^26)";
         return CL2_E_INVALID;
     }
@@ -626,8 +691,8 @@ int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_render
     if (device_ordinal < 0 || device_ordinal >= n_dev) { g_create_error = "device ordinal out of range"; return CL2_E_INVALID; }
     cl2_renderer* r = new cl2_renderer();
     r->device = device_ordinal;
-    r->W = pixel_width; r->H = pixel_height; r->B = pixel_width * pixel_height;
-    const size_t B = (size_t)r->B;
+    r->W = pixel_width; r->H = pixel_height; r->FB = pixel_width * pixel_height;
+    r->streams = 1; r->B = r->FB;
     auto bail = [&](int code) { g_create_error = r->err; cl2_destroy(r); return code; };
     if (hipSetDevice(device_ordinal) != hipSuccess) { r->err = "hipSetDevice failed"; return bail(CL2_E_HIP); }
     if (hipStreamCreate(&r->stream) != hipSuccess || hipStreamCreate(&r->stream_conn) != hipSuccess ||
@@ -642,49 +707,16 @@ int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_render
         if (!ok_ev) { r->err = "hipEventCreate failed"; return bail(CL2_E_HIP); }
     }
     int rc = CL2_OK;
-#define A(ptr, count) if (rc == CL2_OK) rc = dev_alloc(r, &(ptr), (count))
-    A(r->d_seeds, B);
-    for (int q = 0; q < 3; q++) {
-        for (int k = 0; k < 2; k++) {
-            PathBufs& pb = r->sets[q][k];
-            A(pb.P0, MAX_VERTS * B); A(pb.P1, MAX_VERTS * B); A(pb.P2, MAX_VERTS * B); A(pb.P3, MAX_VERTS * B);
-            A(pb.tri, MAX_VERTS * B); A(pb.len, B); A(pb.carry, B);
-        }
-    }
-    A(r->d_hit, B);
-    A(r->d_hit_cam0, B);
-    A(r->d_queue, MAX_VERTS * B);
-    A(r->d_qcount, 9);
-    A(r->d_work, 8);
-    A(r->d_ctag, (size_t)CONN_SLOTS * B);
-    for (int q = 0; q < 2; q++) { A(r->d_chit[q], (size_t)CONN_SLOTS * B); A(r->d_cmask[q], B); }
-    A(r->d_agg, (size_t)AGG_ROWS * B);
-    A(r->d_light_image, B); A(r->d_finalized, B); A(r->d_uni, B);
-    A(r->d_sample_w, B);
-    A(r->d_acc, 8 * B);
-    A(r->d_stats, 1);
-    A(r->d_block_stats, (size_t)grid_for(B) * 4);
-#undef A
+    if (rc == CL2_OK) rc = dev_alloc(r, &r->d_qcount, (size_t)9);
+    if (rc == CL2_OK) rc = dev_alloc(r, &r->d_work, (size_t)8);
+    if (rc == CL2_OK) rc = dev_alloc(r, &r->d_acc, 8 * (size_t)r->FB);
+    if (rc == CL2_OK) rc = dev_alloc(r, &r->d_stats, (size_t)1);
     if (rc != CL2_OK) return bail(rc);
-    unsigned qc[9] = {(unsigned)r->B, 0, 0, 0, 0, 0, 0, 0, 2u * (unsigned)r->B};      // [8]: ray count of the merged level-0 launch
-    bool ok = hipMemcpy(r->d_qcount, qc, sizeof qc, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemset(r->d_light_image, 0, B * sizeof(float4)) == hipSuccess;
-    ok = ok && hipMemset(r->d_finalized, 0, B * sizeof(float4)) == hipSuccess;
-    ok = ok && hipMemset(r->d_uni, 0, B * sizeof(float4)) == hipSuccess;
-    ok = ok && hipMemset(r->d_sample_w, 0, B * sizeof(float)) == hipSuccess;
-    ok = ok && hipMemset(r->d_acc, 0, 8 * B * sizeof(float)) == hipSuccess;
-    ok = ok && hipMemset(r->d_agg, 0, (size_t)AGG_ROWS * B * sizeof(float)) == hipSuccess;
+    bool ok = hipMemset(r->d_acc, 0, 8 * (size_t)r->FB * sizeof(float)) == hipSuccess;
     ok = ok && hipMemset(r->d_stats, 0, sizeof(Stats)) == hipSuccess;
-    ok = ok && hipMemset(r->d_block_stats, 0, (size_t)grid_for(B) * 4 * sizeof(unsigned long long)) == hipSuccess;
-    for (int q = 0; q < 2 && ok; q++) ok = hipMemset(r->d_cmask[q], 0, B * sizeof(unsigned long long)) == hipSuccess;
-    for (int q = 0; q < 3 && ok; q++)
-        for (int k = 0; k < 2 && ok; k++) ok = hipMemset(r->sets[q][k].len, 0, B * sizeof(int)) == hipSuccess;
-    // default seeds: 1 everywhere (xorshift's only forbidden state is 0); callers set real seeds
-    if (ok) {
-        std::vector<uint32_t> ones(2 * B, 1u);
-        ok = hipMemcpy(r->d_seeds, ones.data(), 2 * B * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
-    }
     if (!ok) { r->err = "device buffer initialisation failed"; return bail(CL2_E_HIP); }
+    rc = alloc_pixel_state(r);
+    if (rc != CL2_OK) return bail(rc);
     *out = r;
     return CL2_OK;
 }
@@ -1059,7 +1091,7 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
 
 int cl2_set_seeds(cl2_renderer* r, const uint32_t* seeds, size_t n_words) {
     if (!r || !seeds) return CL2_E_INVALID;
-    if (n_words != 2 * (size_t)r->B) return fail(r, CL2_E_INVALID, "seed buffer must hold 2 words per pixel");
+    if (n_words != 2 * (size_t)r->B) return fail(r, CL2_E_INVALID, "seed buffer must hold 2 words per pixel and sample stream (stream-major)");
     HIP_TRY(r, hipSetDevice(r->device));
     HIP_TRY(r, hipStreamSynchronize(r->stream));
     HIP_TRY(r, hipMemcpy(r->d_seeds, seeds, n_words * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1068,10 +1100,36 @@ int cl2_set_seeds(cl2_renderer* r, const uint32_t* seeds, size_t n_words) {
 
 int cl2_get_seeds(cl2_renderer* r, uint32_t* seeds, size_t n_words) {
     if (!r || !seeds) return CL2_E_INVALID;
-    if (n_words != 2 * (size_t)r->B) return fail(r, CL2_E_INVALID, "seed buffer must hold 2 words per pixel");
+    if (n_words != 2 * (size_t)r->B) return fail(r, CL2_E_INVALID, "seed buffer must hold 2 words per pixel and sample stream (stream-major)");
     HIP_TRY(r, hipSetDevice(r->device));
     HIP_TRY(r, hipStreamSynchronize(r->stream));
     HIP_TRY(r, hipMemcpy(seeds, r->d_seeds, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return CL2_OK;
+}
+
+/* K independent samples of the frame per pass.  Stream k has its own seed words [2*k*W*H, 2*(k+1)*W*H) of
+ * the seed buffer and is exactly what a Renderer with that seed buffer -- rank k of the sample split -- would render; the
+ * accumulators receive the streams' samples in stream order.  Every launch then covers K x W x H entries: a per-level subpath
+ * launch of a 1080p frame is 2 M rays on 524 k resident lanes and all tail; with K = 4 it is the 8.3 M rays of a 4K frame.
+ * Frees and re-allocates the per-pixel state (seeds back to 1: set them again), keeps scene, accumulators and counters. */
+int cl2_set_sample_streams(cl2_renderer* r, int streams) {
+    if (!r) return CL2_E_INVALID;
+    if (streams < 1 || (long long)streams * r->FB >= (1ll << TAG_PID_BITS))
+        return fail(r, CL2_E_INVALID, "sample streams: need streams >= 1 and streams * W * H < 2^26 (pixel-entry bits of a connection tag)");
+    HIP_TRY(r, hipSetDevice(r->device));
+    TRY(drain(r));
+    if (streams == r->streams) return CL2_OK;
+    free_pixel_state(r);
+    r->streams = streams; r->B = streams * r->FB; r->export_stream = 0;
+    r->paths_share = 0; r->levels_auto = 0;                       // launch sizes changed: measure the organisation again
+    return alloc_pixel_state(r);
+}
+int cl2_get_sample_streams(const cl2_renderer* r) { return r ? r->streams : CL2_E_INVALID; }
+/* the stream that cl2_export_* / cl2_import_sample_images address (one frame's worth of records each) */
+int cl2_set_export_stream(cl2_renderer* r, int stream) {
+    if (!r) return CL2_E_INVALID;
+    if (stream < 0 || stream >= r->streams) return fail(r, CL2_E_INVALID, "export stream out of range");
+    r->export_stream = stream;
     return CL2_OK;
 }
 
@@ -1092,7 +1150,7 @@ int cl2_gather_light_image(cl2_renderer* r) { STAGE_PROLOGUE(r); return drain(r)
 int cl2_process_images(cl2_renderer* r) {
     STAGE_PROLOGUE(r);
     TRY(launch_accumulate(r, r->stream));
-    r->samples++;
+    r->samples += (uint64_t)r->streams;
     return drain(r);
 }
 
@@ -1146,7 +1204,7 @@ int run_chunk(cl2_renderer* r, bool pipe, int count) {
         TRY(launch_resolve(r, s_res, set, cs));
         TRY(launch_finalize_accumulate(r, s_res));
         if (pipe) HIP_TRY(r, hipEventRecord(r->ev_res[i % 6], s_res));
-        r->samples++;
+        r->samples += (uint64_t)r->streams;
         // bound the number of in-flight event pairs while profiling
         if (r->profiling && r->spans.size() > 4096) TRY(drain(r));
     }
@@ -1246,10 +1304,10 @@ int cl2_set_pipelining(cl2_renderer* r, int on) {
 
 int cl2_read_accumulators(cl2_renderer* r, float* img, float* wts, int32_t* counts, float* uni, size_t n_pixels) {
     if (!r) return CL2_E_INVALID;
-    if (n_pixels != (size_t)r->B) return fail(r, CL2_E_INVALID, "n_pixels must equal W*H");
+    if (n_pixels != (size_t)r->FB) return fail(r, CL2_E_INVALID, "n_pixels must equal W*H");
     HIP_TRY(r, hipSetDevice(r->device));
     HIP_TRY(r, hipStreamSynchronize(r->stream));
-    const size_t B = r->B;
+    const size_t B = r->FB;
     std::vector<float> h(8 * B);
     HIP_TRY(r, hipMemcpy(h.data(), r->d_acc, 8 * B * sizeof(float), hipMemcpyDeviceToHost));
     for (size_t p = 0; p < B; p++) {
@@ -1265,14 +1323,14 @@ int cl2_reset_accumulators(cl2_renderer* r) {
     if (!r) return CL2_E_INVALID;
     HIP_TRY(r, hipSetDevice(r->device));
     HIP_TRY(r, hipStreamSynchronize(r->stream));
-    HIP_TRY(r, hipMemset(r->d_acc, 0, 8 * (size_t)r->B * sizeof(float)));
+    HIP_TRY(r, hipMemset(r->d_acc, 0, 8 * (size_t)r->FB * sizeof(float)));
     r->samples = 0;
     return CL2_OK;
 }
 
 static int acc_copy(cl2_renderer* r, void* dst, const void* src, size_t n_floats, hipMemcpyKind kind) {
     if (!r || !dst || !src) return CL2_E_INVALID;
-    if (n_floats != 8 * (size_t)r->B) return fail(r, CL2_E_INVALID, "packed accumulators hold 8*W*H floats");
+    if (n_floats != 8 * (size_t)r->FB) return fail(r, CL2_E_INVALID, "packed accumulators hold 8*W*H floats");
     HIP_TRY(r, hipSetDevice(r->device));
     TRY(drain(r));
     HIP_TRY(r, hipMemcpy(dst, src, n_floats * sizeof(float), kind));
@@ -1285,7 +1343,7 @@ int cl2_write_accumulators_packed(cl2_renderer* r, const float* src, size_t n) {
 namespace {
 int tone_buffers(cl2_renderer* r) {
     if (!r->d_tone_partial) TRY(dev_alloc(r, &r->d_tone_partial, (size_t)TONE_BLOCKS + 1));
-    if (!r->d_tone_out) TRY(dev_alloc(r, &r->d_tone_out, (size_t)3 * r->B));
+    if (!r->d_tone_out) TRY(dev_alloc(r, &r->d_tone_out, (size_t)3 * r->FB));
     return CL2_OK;
 }
 }  // namespace
@@ -1296,8 +1354,8 @@ int cl2_tone_log_sum(cl2_renderer* r, int which, double* sum_out) {
     HIP_TRY(r, hipSetDevice(r->device));
     TRY(drain(r));
     TRY(tone_buffers(r));
-    const int grid = std::min(grid_for(r->B), TONE_BLOCKS);
-    hipLaunchKernelGGL(k_tone_logsum, dim3(grid), dim3(256), 0, r->stream, r->d_acc, r->B, which, r->d_tone_partial);
+    const int grid = std::min(grid_for(r->FB), TONE_BLOCKS);
+    hipLaunchKernelGGL(k_tone_logsum, dim3(grid), dim3(256), 0, r->stream, r->d_acc, r->FB, which, r->d_tone_partial);
     hipLaunchKernelGGL(k_tone_logsum_final, dim3(1), dim3(256), 0, r->stream, r->d_tone_partial, grid, r->d_tone_partial + TONE_BLOCKS);
     HIP_TRY(r, hipGetLastError());
     HIP_TRY(r, hipMemcpyAsync(sum_out, r->d_tone_partial + TONE_BLOCKS, sizeof(double), hipMemcpyDeviceToHost, r->stream));
@@ -1308,11 +1366,11 @@ int cl2_tone_log_sum(cl2_renderer* r, int which, double* sum_out) {
 int cl2_tone_map(cl2_renderer* r, int which, double exposure, double white_point, double log_average, uint8_t* out_bgr, size_t n_bytes) {
     if (!r || !out_bgr) return CL2_E_INVALID;
     if (which < 0 || which > 2) return fail(r, CL2_E_INVALID, "picture: 0 image, 1 unweighted_image, 2 unidirectional_image");
-    if (n_bytes != (size_t)3 * r->B) return fail(r, CL2_E_INVALID, "the tone-mapped picture holds 3*W*H bytes");
+    if (n_bytes != (size_t)3 * r->FB) return fail(r, CL2_E_INVALID, "the tone-mapped picture holds 3*W*H bytes");
     HIP_TRY(r, hipSetDevice(r->device));
     TRY(drain(r));
     TRY(tone_buffers(r));
-    hipLaunchKernelGGL(k_tone_apply, dim3(grid_for(r->B)), dim3(256), 0, r->stream, r->d_acc, r->B, which, exposure, white_point * white_point,
+    hipLaunchKernelGGL(k_tone_apply, dim3(grid_for(r->FB)), dim3(256), 0, r->stream, r->d_acc, r->FB, which, exposure, white_point * white_point,
                        log_average, r->d_tone_out);
     HIP_TRY(r, hipGetLastError());
     HIP_TRY(r, hipMemcpyAsync(out_bgr, r->d_tone_out, n_bytes, hipMemcpyDeviceToHost, r->stream));
@@ -1467,7 +1525,7 @@ int cl2_reduce_accumulators(cl2_renderer* r) {
         const int rc = drain(r);
         if (rc != CL2_OK) { r->comm_poisoned = true; comm_abort(r, api); return rc; }
     }
-    COMM_RCCL_TRY(r, api, api->AllReduce(r->d_acc, r->d_acc, 8 * (size_t)r->B, ncclFloat, ncclSum, r->comm, r->stream));
+    COMM_RCCL_TRY(r, api, api->AllReduce(r->d_acc, r->d_acc, 8 * (size_t)r->FB, ncclFloat, ncclSum, r->comm, r->stream));
     return comm_wait(r, api, "cl2_reduce_accumulators");
 }
 
@@ -1608,6 +1666,7 @@ int cl2_query_organisation(cl2_renderer* r, cl2_organisation* out) {
     out->pruned_records = r->bvh.n_fast_nodes;
     out->wide_connections = (wide_walk(r) && split_conn(r)) ? 1 : 0;
     out->tree_bytes = (int64_t)r->bvh.n_nodes * 32 + (int64_t)r->bvh.n_tris * 48;
+    out->sample_streams = r->streams;
     return CL2_OK;
 }
 int cl2_set_debug_flags(cl2_renderer* r, int flags) {
@@ -1671,61 +1730,61 @@ int cl2_reset_counters(cl2_renderer* r) {
 
 int cl2_export_rays(cl2_renderer* r, int which, void* out, size_t n_records) {
     STAGE_PROLOGUE(r);
-    if (!out || (which != CL2_LIGHT && which != CL2_CAMERA) || n_records != (size_t)r->B) return fail(r, CL2_E_INVALID, "bad export_rays arguments");
+    if (!out || (which != CL2_LIGHT && which != CL2_CAMERA) || n_records != (size_t)r->FB) return fail(r, CL2_E_INVALID, "bad export_rays arguments");
     RayRec* d = nullptr;
-    TRY(dev_alloc(r, &d, (size_t)r->B));
-    hipLaunchKernelGGL(k_export_rays, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->sets[r->cur][which], which == CL2_CAMERA ? 1 : 0, d);
+    TRY(dev_alloc(r, &d, (size_t)r->FB));
+    hipLaunchKernelGGL(k_export_rays, dim3(grid_for(r->FB)), dim3(BLOCK), 0, r->stream, r->FB, r->export_stream * r->FB, r->sets[r->cur][which], which == CL2_CAMERA ? 1 : 0, d);
     int rc = drain(r);
-    if (rc == CL2_OK && hipMemcpy(out, d, (size_t)r->B * sizeof(RayRec), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(r, CL2_E_HIP, "export copy failed");
+    if (rc == CL2_OK && hipMemcpy(out, d, (size_t)r->FB * sizeof(RayRec), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(r, CL2_E_HIP, "export copy failed");
     dev_free(r, d);
     return rc;
 }
 
 int cl2_export_paths(cl2_renderer* r, int which, void* out, size_t n_records) {
     STAGE_PROLOGUE(r);
-    if (!out || (which != CL2_LIGHT && which != CL2_CAMERA) || n_records != (size_t)r->B) return fail(r, CL2_E_INVALID, "bad export_paths arguments");
+    if (!out || (which != CL2_LIGHT && which != CL2_CAMERA) || n_records != (size_t)r->FB) return fail(r, CL2_E_INVALID, "bad export_paths arguments");
     unsigned char* d = nullptr;
-    TRY(dev_alloc(r, &d, (size_t)r->B * 1040));
-    hipLaunchKernelGGL(k_export_paths, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->sets[r->cur][which], which == CL2_CAMERA ? 1 : 0, d);
+    TRY(dev_alloc(r, &d, (size_t)r->FB * 1040));
+    hipLaunchKernelGGL(k_export_paths, dim3(grid_for(r->FB)), dim3(BLOCK), 0, r->stream, r->FB, r->export_stream * r->FB, r->B, r->sets[r->cur][which], which == CL2_CAMERA ? 1 : 0, d);
     int rc = drain(r);
-    if (rc == CL2_OK && hipMemcpy(out, d, (size_t)r->B * 1040, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(r, CL2_E_HIP, "export copy failed");
+    if (rc == CL2_OK && hipMemcpy(out, d, (size_t)r->FB * 1040, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(r, CL2_E_HIP, "export copy failed");
     dev_free(r, d);
     return rc;
 }
 
 int cl2_export_aggregators(cl2_renderer* r, void* out, size_t n_records) {
     STAGE_PROLOGUE(r);
-    if (!out || n_records != (size_t)r->B) return fail(r, CL2_E_INVALID, "bad export_aggregators arguments");
+    if (!out || n_records != (size_t)r->FB) return fail(r, CL2_E_INVALID, "bad export_aggregators arguments");
     float* d = nullptr;
-    TRY(dev_alloc(r, &d, (size_t)r->B * 32));
-    hipLaunchKernelGGL(k_export_aggregators, dim3(grid_for(r->B)), dim3(BLOCK), 0, r->stream, r->B, r->d_agg, d);
+    TRY(dev_alloc(r, &d, (size_t)r->FB * 32));
+    hipLaunchKernelGGL(k_export_aggregators, dim3(grid_for(r->FB)), dim3(BLOCK), 0, r->stream, r->FB, r->export_stream * r->FB, r->B, r->d_agg, d);
     int rc = drain(r);
-    if (rc == CL2_OK && hipMemcpy(out, d, (size_t)r->B * 128, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(r, CL2_E_HIP, "export copy failed");
+    if (rc == CL2_OK && hipMemcpy(out, d, (size_t)r->FB * 128, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(r, CL2_E_HIP, "export copy failed");
     dev_free(r, d);
     return rc;
 }
 
 int cl2_export_sample_images(cl2_renderer* r, float* fin4, float* light4, float* sw, float* uni4, size_t n_pixels) {
     STAGE_PROLOGUE(r);
-    if (n_pixels != (size_t)r->B) return fail(r, CL2_E_INVALID, "n_pixels must equal W*H");
+    if (n_pixels != (size_t)r->FB) return fail(r, CL2_E_INVALID, "n_pixels must equal W*H");
     TRY(drain(r));
-    const size_t B = r->B;
-    if (fin4) HIP_TRY(r, hipMemcpy(fin4, r->d_finalized, B * sizeof(float4), hipMemcpyDeviceToHost));
-    if (light4) HIP_TRY(r, hipMemcpy(light4, r->d_light_image, B * sizeof(float4), hipMemcpyDeviceToHost));
-    if (sw) HIP_TRY(r, hipMemcpy(sw, r->d_sample_w, B * sizeof(float), hipMemcpyDeviceToHost));
-    if (uni4) HIP_TRY(r, hipMemcpy(uni4, r->d_uni, B * sizeof(float4), hipMemcpyDeviceToHost));
+    const size_t B = r->FB, off = (size_t)r->export_stream * r->FB;
+    if (fin4) HIP_TRY(r, hipMemcpy(fin4, r->d_finalized + off, B * sizeof(float4), hipMemcpyDeviceToHost));
+    if (light4) HIP_TRY(r, hipMemcpy(light4, r->d_light_image + off, B * sizeof(float4), hipMemcpyDeviceToHost));
+    if (sw) HIP_TRY(r, hipMemcpy(sw, r->d_sample_w + off, B * sizeof(float), hipMemcpyDeviceToHost));
+    if (uni4) HIP_TRY(r, hipMemcpy(uni4, r->d_uni + off, B * sizeof(float4), hipMemcpyDeviceToHost));
     return CL2_OK;
 }
 
 int cl2_import_sample_images(cl2_renderer* r, const float* fin4, const float* light4, const float* sw, const float* uni4, size_t n_pixels) {
     STAGE_PROLOGUE(r);
-    if (n_pixels != (size_t)r->B) return fail(r, CL2_E_INVALID, "n_pixels must equal W*H");
+    if (n_pixels != (size_t)r->FB) return fail(r, CL2_E_INVALID, "n_pixels must equal W*H");
     TRY(drain(r));
-    const size_t B = r->B;
-    if (fin4) HIP_TRY(r, hipMemcpy(r->d_finalized, fin4, B * sizeof(float4), hipMemcpyHostToDevice));
-    if (light4) HIP_TRY(r, hipMemcpy(r->d_light_image, light4, B * sizeof(float4), hipMemcpyHostToDevice));
-    if (sw) HIP_TRY(r, hipMemcpy(r->d_sample_w, sw, B * sizeof(float), hipMemcpyHostToDevice));
-    if (uni4) HIP_TRY(r, hipMemcpy(r->d_uni, uni4, B * sizeof(float4), hipMemcpyHostToDevice));
+    const size_t B = r->FB, off = (size_t)r->export_stream * r->FB;
+    if (fin4) HIP_TRY(r, hipMemcpy(r->d_finalized + off, fin4, B * sizeof(float4), hipMemcpyHostToDevice));
+    if (light4) HIP_TRY(r, hipMemcpy(r->d_light_image + off, light4, B * sizeof(float4), hipMemcpyHostToDevice));
+    if (sw) HIP_TRY(r, hipMemcpy(r->d_sample_w + off, sw, B * sizeof(float), hipMemcpyHostToDevice));
+    if (uni4) HIP_TRY(r, hipMemcpy(r->d_uni + off, uni4, B * sizeof(float4), hipMemcpyHostToDevice));
     return CL2_OK;
 }
 

@@ -36,15 +36,25 @@ def make_seeds(batch_size, seed=20240928, rank=0):
     return s
 
 
+def stream_seeds(batch_size, streams, seed=20240928, first_rank=0):
+    """Seed buffers of `streams` sample streams: stream k gets `make_seeds(batch, seed, first_rank + k)`, the buffer rank
+    first_rank + k of a sample split would use.  Shape (batch, 2) for one stream, else (streams, batch, 2)."""
+    if streams == 1:
+        return make_seeds(batch_size, seed, first_rank)
+    return np.stack([make_seeds(batch_size, seed, first_rank + k) for k in range(streams)])
+
+
 def next_power_of_two(n):
     return 1 << (n - 1).bit_length() if n > 0 else 1
 
 
 class Renderer:
-    def __init__(self, scene, kernel_path=None, seeds=None, device=0, variant=None):
+    def __init__(self, scene, kernel_path=None, seeds=None, device=0, variant=None, streams=1):
         # kernel_path is accepted for signature compatibility (the reference JIT-compiles
         # trace.metal from it, renderer.py:27-29); the HIP kernels are precompiled.
         # variant="test" loads libclive2_amd_test.so (carries the cross-check resolve kernel).
+        # streams=K: K independent samples of the frame per pass, one seed buffer each (what K reference Renderers --
+        # the ranks of a sample split -- would render); seeds then has shape (K, batch, 2).  Default 1 = the reference.
         self._h = C.c_void_p()
         self._L = _native.lib(variant)
         self.scene = scene
@@ -57,8 +67,11 @@ class Renderer:
             self._h = C.c_void_p()
             raise RendererError(f"cl2_create failed ({rc}): {msg.decode() if msg else ''}")
         self.samples = 0
+        self.streams = 1
         self.upload_scene(scene)
-        self.set_seeds(make_seeds(self.batch_size) if seeds is None else seeds)
+        if int(streams) != 1:
+            self.set_sample_streams(streams)
+        self.set_seeds(stream_seeds(self.batch_size, self.streams) if seeds is None else seeds)
 
     # ---- plumbing ----
     _FATAL = (-2, -5)                    # CL2_E_HIP, CL2_E_COMM (include/clive2_amd.h): the device or the communicator is gone
@@ -92,14 +105,27 @@ class Renderer:
         self._check(self._L.cl2_upload_scene(self._h, ptr(boxes), len(boxes), ptr(tris), len(tris), ptr(mats), len(mats),
                                              ptr(cam), ptr(ltris), ptr(areas), ptr(lidx), n_light), "cl2_upload_scene")
 
+    def set_sample_streams(self, streams):
+        """K independent samples of the frame per pass (cl2_set_sample_streams): frees and re-allocates the per-pixel device
+        state, so the seeds must be set again -- `set_seeds` of shape (K, batch, 2), stream k = the buffer Renderer k of a
+        sample split would own.  Accumulators, scene and counters are kept."""
+        self._check(self._L.cl2_set_sample_streams(self._h, int(streams)), "cl2_set_sample_streams")
+        self.streams = int(streams)
+
+    def set_export_stream(self, stream):
+        """The sample stream that export_rays / export_paths / export_aggregators / {ex,im}port_sample_images address."""
+        self._check(self._L.cl2_set_export_stream(self._h, int(stream)), "cl2_set_export_stream")
+
     def set_seeds(self, seeds):
         s = np.ascontiguousarray(seeds, dtype=np.uint32)
-        if s.size != 2 * self.batch_size:
-            raise RendererError(f"seed buffer needs {2 * self.batch_size} uint32 words, got {s.size}")
+        if s.size != 2 * self.batch_size * self.streams:
+            raise RendererError(f"seed buffer needs {2 * self.batch_size * self.streams} uint32 words, got {s.size}")
         self._check(self._L.cl2_set_seeds(self._h, ptr(s), C.c_size_t(s.size)), "cl2_set_seeds")
 
     def get_random_buffer(self):
-        s = np.empty((self.batch_size, 2), dtype=np.uint32)
+        """(batch, 2) uint32 as the reference's rand_buffer; (streams, batch, 2) with more than one sample stream."""
+        shape = (self.batch_size, 2) if self.streams == 1 else (self.streams, self.batch_size, 2)
+        s = np.empty(shape, dtype=np.uint32)
         self._check(self._L.cl2_get_seeds(self._h, ptr(s), C.c_size_t(s.size)), "cl2_get_seeds")
         return s
 
@@ -141,8 +167,9 @@ class Renderer:
         self.run_samples(1)
 
     def run_samples(self, n):
+        """n passes of the pipeline = n x run_sample (n * streams samples of the frame with more than one sample stream)."""
         self._check(self._L.cl2_run_samples(self._h, int(n)), "run_samples")
-        self.samples += int(n)
+        self.samples += int(n) * self.streams
 
     # ---- accumulators (renderer.py:41-45) ----
     def read_accumulators(self):
@@ -305,7 +332,7 @@ class Renderer:
         """Make the measured launch-organisation choices now (cl2_tune); returns the number of (real) samples it rendered."""
         n = C.c_int(0)
         self._check(self._L.cl2_tune(self._h, C.byref(n)), "cl2_tune")
-        self.samples += n.value
+        self.samples += n.value * self.streams
         return n.value
 
     def counters(self):

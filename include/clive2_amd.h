@@ -101,8 +101,22 @@ int cl2_upload_scene(cl2_renderer* r,
                      const int32_t* light_triangle_indices, int light_count);
 
 /* -- RNG state: the (batch,2) uint32 xorshift buffer of src/renderer.py:54,86-87 -- */
+/*    n_words = 2 * streams * W * H (stream-major; see cl2_set_sample_streams) */
 int cl2_set_seeds(cl2_renderer* r, const uint32_t* seeds, size_t n_words);
 int cl2_get_seeds(cl2_renderer* r, uint32_t* seeds, size_t n_words);
+
+/* -- sample streams: K independent samples of the frame per pass.  The reference's Renderer owns ONE seed buffer
+ *    (src/renderer.py:54, :86-87), so K renderers -- the ranks of the sample split, SURVEY 8e -- own K; a handle with K
+ *    streams holds those K buffers (seed words [2 k W H, 2 (k+1) W H) belong to stream k) and every stage call / every
+ *    pass of cl2_run_samples renders one sample of EACH stream, stream k being exactly what a handle seeded with buffer k
+ *    alone would render; the accumulators receive the streams' samples in stream order.  What it buys: every launch carries
+ *    K x W x H work items (a per-level subpath launch of a 1080p frame is 2 M rays on 524 k resident lanes -- all tail).
+ *    Default 1 = the reference's single-buffer sequence.  Needs K * W * H < 2^26.  The call frees and re-allocates the
+ *    per-pixel device state (seeds return to 1; scene, accumulators and counters are kept).
+ *    cl2_set_export_stream picks the stream that cl2_export_* and cl2_{ex,im}port_sample_images address. -- */
+int cl2_set_sample_streams(cl2_renderer* r, int streams);
+int cl2_get_sample_streams(const cl2_renderer* r);
+int cl2_set_export_stream(cl2_renderer* r, int stream);
 
 /* -- the per-sample pipeline.  The eight stage calls mirror Renderer's stage methods
  *    (src/renderer.py:113-278) for stage-level parity work; cl2_run_samples(n) is
@@ -229,6 +243,8 @@ typedef struct {
     int32_t pruned_records;         /* records of the pruned table of an LDS-resident tree (inner boxes whose test costs more than it saves are
                                        dropped: exact for rays with finite 1/d); 0: none */
     int64_t tree_bytes;             /* 32 B per record + 48 B per intersection triangle */
+    int32_t sample_streams;         /* cl2_set_sample_streams */
+    int32_t reserved;
 } cl2_organisation;
 int cl2_query_organisation(cl2_renderer* r, cl2_organisation* out);
 

@@ -455,3 +455,40 @@ def test_config5_4k_vs_oracle(interior_real, oracle_mod):
     """... and at the config's own 3840x2160 (8.3 M pixels: 23-bit pixel ids in the connection tags, per-level subpath
     launches in the serial order): one sample, Path[] included (2 x 8.6 GB per side)."""
     _full_frame_vs_oracle(interior_real.with_resolution(3840, 2160), oracle_mod, more=0)
+
+
+def test_config3_1080p_four_sample_streams_vs_oracle(oracle_mod):
+    """Sample streams at full size (cl2_set_sample_streams, tests/test_gpu_streams.py): config 3 at 1920x1080 with K = 4 --
+    every launch carries 8.3 M entries, the pixel ids of the connection tags have 23 bits -- two pipelined passes against
+    four oracle renderers on the four seed buffers, one after the other (a 1080p oracle holds 5 GB of Path records)."""
+    from clive2_amd.renderer import Renderer
+    scene = _glass(4, 1920, 1080)
+    B, K, passes = 1920 * 1080, 4, 2
+    r = Renderer(scene, streams=K)
+    r.run_samples(passes)
+    assert r.organisation()["sample_streams"] == K and r.samples == K * passes
+    seeds = r.get_random_buffer()
+    img_sum = np.zeros((1080, 1920, 3), np.float64)
+    wts_sum = np.zeros((1080, 1920, 1), np.float64)
+    uni_sum = np.zeros((1080, 1920, 3), np.float64)
+    rays = 0
+    for k in range(K):
+        o = oracle_mod.OracleRenderer(scene, seeds=oracle_mod.make_seeds(B, rank=k))
+        for _ in range(passes):
+            o.run_sample()
+        assert np.array_equal(seeds[k], o.rand_buffer)
+        r.set_export_stream(k)
+        assert _same_bytes(r.export_paths(LIGHT), o.out_light_paths)
+        assert _same_bytes(r.export_paths(CAMERA), o.out_camera_paths)
+        agg = r.export_aggregators()
+        for f in ("total_contribution", "weights", "contrib_weight_sum"):
+            assert _same_bytes(agg[f], o.weight_aggregators[f]), (k, f)
+        img_sum += o.summed_image; wts_sum += o.summed_sample_weights; uni_sum += o.unidirectional_image_buffer
+        rays += o.rays_traced
+        del o
+    img, wts, cnt, uni = r.read_accumulators()
+    assert (cnt == K * passes).all() and r.counters()["rays"] == rays
+    np.testing.assert_allclose(img, img_sum, rtol=5e-5, atol=1e-8)
+    np.testing.assert_allclose(wts, wts_sum, rtol=5e-5, atol=1e-8)
+    np.testing.assert_allclose(uni, uni_sum, rtol=2e-6, atol=0)
+    r.close()
