@@ -43,6 +43,12 @@ constexpr int WIDE_STACK_LDS = 8;
 // whole-subpath launch 5.87 -> 6.30 ms on the glass scene, connection launch of the 1M-triangle scene 15.8 -> 16.3 ms.)
 constexpr int WIDE_STACK_OVERFLOW = 136;      // 2 x the reference's 64-entry stack bound + slack: cannot be exceeded (Q18 check at upload)
 
+#ifdef CL2_WALK_HISTO
+// instrumentation build only (tools/exp_walk_histo.py): per pass of the wide walk, how many lanes visit a node / test triangles
+// (first and second pair round) / are idle, and how many triangles a leaf has when it is entered
+__device__ unsigned long long g_walk_histo[6][65];
+#endif
+
 struct WideView {
     const float4* nodes;       // 8 float4 per wide node
     const float4* tris;        // 3 float4 per triangle (the binary walk's array)
@@ -53,20 +59,46 @@ struct WideView {
     int n_lds_nodes;           // wide nodes [0, n_lds_nodes) (breadth-first numbering: the top of the tree) staged in LDS
 };
 
+// Round 4: the pass rewritten for its instruction count.  The ISA of round 3's loop showed what a pass paid beside its arithmetic:
+// the node record came by FLAT loads (a per-lane select between the LDS window and global memory is a generic pointer: such a load
+// waits on BOTH memory counters) and in two dependent rounds (the fourth slot's bounds were loaded under `ref != EMPTY`); stack pops
+// were flat loads too (LDS entry or global overflow entry, one selected pointer); every conditional push, every early exit of the
+// triangle test and every skipped slot was an exec-mask region (3-4 scalar instructions each: ~310 scalar per ~600 vector
+// instructions per pass, at the one-per-two ratio where the CU's single scalar unit binds, tools/issue_mix.hip); LDS addresses were
+// computed with a multiply by blockDim.x; SGPRs spilled into VGPR lanes.  Here:
+//   * a node visit is 7 x 16-byte global loads issued together, four unconditional slab tests (an empty slot holds a box at
+//     +inf, which can never pass `tmin <= tmax && tmin < best_t`: cl2_upload_scene) and three UNCONDITIONAL 8-byte LDS writes
+//     of the candidate found so far with `sp += pushed` -- no exec-mask region at all.  Lanes within three entries of the LDS
+//     part's end take the conditional form with the global overflow array (rare, wave-level branch);
+//   * the stack is int2 {ref, tmin} per entry ([entry][thread], one ds_read_b64 / ds_write_b64), 8 entries in LDS, addressed
+//     by shift; the overflow accesses are `volatile` so that they cannot be merged with the LDS ones into a flat access;
+//   * the triangle test has no early exits: in a wave of 40 lanes testing 40 different triangles some lane always passes the
+//     `u` test, so the exits only cost scalar instructions; one predicated update at the end, identical decisions
+//     (NaN included: `!(u < 0 || u > 1)` etc. are kept in that form).  The second triangle of a pair is tested
+//     unconditionally: a leaf with an odd count re-tests its last triangle, which cannot pass `t < best_t` a second time;
+//   * no LDS window of the top of the tree by default: plain global loads served by L1 / L2 (a window can still be asked for:
+//     its lanes read LDS in their own branch, kept apart from the global one).
+// Per ray the sequence of box tests, triangle tests and comparisons is unchanged (same parity tests, same fuzz).
+constexpr int WIDE_NT = 256;                  // threads per workgroup of the wide launches (BLOCK)
+constexpr int WIDE_S = WIDE_STACK_LDS;        // stack entries per lane in LDS
+
 template <bool COUNT, bool TWO_TRIS, class Source>
 __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, const BvhView& b, unsigned n, unsigned* work_counter, const Source& src,
                                                          unsigned& n_box, unsigned& n_tri) {
+    static_assert(!COUNT, "the node-test tallies are defined by the binary walk");
     extern __shared__ float4 cl2_tree_lds[];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int S = w.stack_lds;
-    float4* s_nodes = cl2_tree_lds;                                                     // [8 * n_lds_nodes]
-    int* s_ref = reinterpret_cast<int*>(cl2_tree_lds + 8 * w.n_lds_nodes);              // [S][blockDim.x]
-    float* s_tmin = reinterpret_cast<float*>(s_ref) + S * nt;
-    for (int i = tid; i < 8 * w.n_lds_nodes; i += nt) s_nodes[i] = w.nodes[i];
-    __syncthreads();
-    int2* ovf = w.overflow + ((size_t)blockIdx.x * nt + tid) * w.ovf_stride;
+    const int tid = threadIdx.x;
+    constexpr int NT = WIDE_NT;
+    const int n_win = w.n_lds_nodes;
+    float4* s_nodes = cl2_tree_lds;                                                     // [8 * n_win]
+    int2* s_stack = reinterpret_cast<int2*>(cl2_tree_lds + 8 * n_win) + tid;            // entry e of this lane: s_stack[e * NT]
+    if (n_win > 0) {
+        for (int i = tid; i < 8 * n_win; i += NT) s_nodes[i] = w.nodes[i];
+        __syncthreads();
+    }
+    volatile int* ovf = reinterpret_cast<volatile int*>(w.overflow + ((size_t)blockIdx.x * NT + tid) * w.ovf_stride);
     const int lane = tid & 63;
-    const unsigned waves = gridDim.x * (blockDim.x >> 6);
+    const unsigned waves = gridDim.x * (NT >> 6);
     unsigned chunk = n / (waves * 4u);
     chunk = chunk < 64u ? 64u : (chunk > (unsigned)RAY_CHUNK_MAX ? (unsigned)RAY_CHUNK_MAX : chunk);
     unsigned w_next = 0, w_end = 0;
@@ -81,22 +113,23 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
     const int n_nodes = b.n_nodes;
     int key = 0;                               // the source's token of the lane's ray (pixel id / tag): store() needs it again
 
-    auto push = [&](int ref, float tmin) {
-        if (sp < S) { s_ref[sp * nt + tid] = ref; s_tmin[sp * nt + tid] = tmin; }
-        else ovf[sp - S] = make_int2(ref, __float_as_int(tmin));
-        sp++;
+    auto take = [&](int ref) {                 // a stack entry / slot reference becomes the lane's next piece of work
+        if (ref >= 0) cur = ref;
+        else { const int info = ~ref; tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
     };
-    // next work item of the lane: pops until an entry still passes `tmin < best_t` (the reference's test of that box
-    // at this moment) or the stack is empty
-    auto pop_next = [&]() {
-        while (sp > 0 && cur < 0 && tri_i >= tri_end) {
-            sp--;
-            int ref; float tmin;
-            if (sp < S) { ref = s_ref[sp * nt + tid]; tmin = s_tmin[sp * nt + tid]; }
-            else { const int2 e = ovf[sp - S]; ref = e.x; tmin = __int_as_float(e.y); }
-            if (!(tmin < best.t)) continue;
-            if (ref >= 0) cur = ref;
-            else { const int info = ~ref; tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
+    // Lanes with nothing in hand pop until an entry still passes `tmin < best_t` (the reference's test of that box at this
+    // moment) or their stack is empty.  A wave-level loop: one ds_read_b64 per lane and round.
+    auto pop_loop = [&]() {
+        bool need = active && wlane && cur < 0 && tri_i >= tri_end && sp > 0;
+        while (__any(need)) {
+            if (need) {
+                sp--;
+                int ref, tbits;
+                if (sp < WIDE_S) { const int2 e = s_stack[sp * NT]; ref = e.x; tbits = e.y; }
+                else { ref = ovf[2 * (sp - WIDE_S)]; tbits = ovf[2 * (sp - WIDE_S) + 1]; }
+                if (__int_as_float(tbits) < best.t) { take(ref); need = false; }
+                else need = sp > 0;
+            }
         }
     };
 
@@ -130,7 +163,6 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
                     const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
                                                        __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
                     const float tmax = __builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
-                    if (COUNT) n_box++;
                     if (tmin <= tmax && tmin < best.t) cur = 0;
                 }
             }
@@ -139,77 +171,152 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
             idle = __ballot(!active);
         }
         if (!__any(active)) break;
+#ifdef CL2_WALK_HISTO
+        bool h_node = false, h_t0 = false, h_t1 = false;
+        const int h_tri_before = tri_end - tri_i;
+#endif
 
-        if (active) {
-            if (!wlane) {
-                if (tri_i >= tri_end && node < n_nodes) {
-                    const float4 lo = b.nodes[2 * node], hi = b.nodes[2 * node + 1];
-                    const int next = __float_as_int(lo.w);
-                    const float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
-                    const float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
-                    const float tmin = max_msl(max_msl(min_msl(t0x, t1x), min_msl(t0y, t1y)), max_msl(min_msl(t0z, t1z), 0.0f));
-                    const float tmax = min_msl(min_msl(max_msl(t0x, t1x), max_msl(t0y, t1y)), min_msl(max_msl(t0z, t1z), __builtin_inff()));
-                    node = next;
-                    if (tmin <= tmax && tmin < best.t) {
-                        const int info = __float_as_int(hi.w);
-                        if (info < 0) node = ~info;
-                        else { tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
-                    }
+        // ---- rays with a non-finite 1/d: one node of the binary stackless walk (records through the caches, MSL min / max) ----
+        if (__any(active && !wlane)) {
+            if (active && !wlane && tri_i >= tri_end && node < n_nodes) {
+                const float4 lo = b.nodes[2 * node], hi = b.nodes[2 * node + 1];
+                const int next = __float_as_int(lo.w);
+                const float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
+                const float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
+                const float tmin = max_msl(max_msl(min_msl(t0x, t1x), min_msl(t0y, t1y)), max_msl(min_msl(t0z, t1z), 0.0f));
+                const float tmax = min_msl(min_msl(max_msl(t0x, t1x), max_msl(t0y, t1y)), min_msl(max_msl(t0z, t1z), __builtin_inff()));
+                node = next;
+                if (tmin <= tmax && tmin < best.t) {
+                    const int info = __float_as_int(hi.w);
+                    if (info < 0) node = ~info;
+                    else { tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
                 }
-            } else {
-            pop_next();                                                     // lanes that finished a leaf in the previous pass
-            if (cur >= 0) {
-                // one wide node: the slab tests of up to four boxes, in the reference's visit order (slot 0 first)
-                const float4* nd = cur < w.n_lds_nodes ? s_nodes + 8 * cur : w.nodes + (size_t)8 * cur;
-                const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
-                const float4 rf = nd[6];
+            }
+        }
+
+        pop_loop();                                                         // lanes that finished a leaf in the previous pass
+        // ---- one wide node per lane that stands at one: the slab tests of its four boxes in the reference's visit order ----
+        const bool visit = active && wlane && cur >= 0;
+#ifdef CL2_WALK_HISTO
+        h_node = visit;
+#endif
+        if (__any(visit)) {
+            if (visit) {
+                float4 lx, ly, lz, hx, hy, hz, rf;
+                if (n_win > 0 && cur < n_win) {
+                    const float4* nd = s_nodes + 8 * cur;
+                    lx = nd[0]; ly = nd[1]; lz = nd[2]; hx = nd[3]; hy = nd[4]; hz = nd[5]; rf = nd[6];
+                    asm volatile("" ::: "memory");                          // keeps this branch's LDS reads apart from the global loads below
+                } else {
+                    const float4* __restrict__ nd = w.nodes + (size_t)8 * cur;
+                    lx = nd[0]; ly = nd[1]; lz = nd[2]; hx = nd[3]; hy = nd[4]; hz = nd[5]; rf = nd[6];
+                }
                 cur = -1;
                 const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
                 const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
                 const int ref[4] = {__float_as_int(rf.x), __float_as_int(rf.y), __float_as_int(rf.z), __float_as_int(rf.w)};
-                // slots are tested last to first and pushed, so that the first one pops first -- except the one that WOULD pop
-                // first: it is what the lane does next anyway (it has just passed `tmin < best_t`, and best_t has not moved),
-                // so it never goes through the stack (one LDS write + read less per visit, one entry less of depth)
-                int next_ref = WIDE_EMPTY;
-                float next_tmin = 0.0f;
+                float tm[4];
+                bool pass[4];
 #pragma unroll
-                for (int k = 3; k >= 0; k--) {
-                    if (ref[k] == WIDE_EMPTY) continue;
+                for (int k = 0; k < 4; k++) {
                     const float t0x = (lox[k] - o.x) * inv.x, t0y = (loy[k] - o.y) * inv.y, t0z = (loz[k] - o.z) * inv.z;
                     const float t1x = (hix[k] - o.x) * inv.x, t1y = (hiy[k] - o.y) * inv.y, t1z = (hiz[k] - o.z) * inv.z;
                     const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
                                                        __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
                     const float tmax = __builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
-                    if (COUNT) n_box++;
-                    if (tmin <= tmax && tmin < best.t) {
-                        if (next_ref != WIDE_EMPTY) push(next_ref, next_tmin);
-                        next_ref = ref[k]; next_tmin = tmin;
+                    tm[k] = tmin;
+                    pass[k] = tmin <= tmax && tmin < best.t;                // an empty slot's box lies at +inf: never
+                }
+                // Slots are taken last to first, so that the first one pops first; the candidate found so far is pushed when
+                // another slot passes in front of it, and the one left at the end -- the slot that WOULD pop first -- is what the
+                // lane does next (it has just passed `tmin < best_t`, and best_t has not moved): it never goes through the stack.
+                int next_ref = pass[3] ? ref[3] : WIDE_EMPTY;
+                float next_tmin = tm[3];
+                if (!__any(sp + 3 > WIDE_S)) {
+                    // all three possible pushes fit the LDS part: the candidate is WRITTEN unconditionally above the top of the
+                    // stack and only `sp` says whether it was pushed
+#pragma unroll
+                    for (int k = 2; k >= 0; k--) {
+                        s_stack[sp * NT] = make_int2(next_ref, __float_as_int(next_tmin));
+                        sp += (pass[k] && next_ref != WIDE_EMPTY) ? 1 : 0;
+                        next_ref = pass[k] ? ref[k] : next_ref;
+                        next_tmin = pass[k] ? tm[k] : next_tmin;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 2; k >= 0; k--) {
+                        if (pass[k]) {
+                            if (next_ref != WIDE_EMPTY) {
+                                if (sp < WIDE_S) s_stack[sp * NT] = make_int2(next_ref, __float_as_int(next_tmin));
+                                else { ovf[2 * (sp - WIDE_S)] = next_ref; ovf[2 * (sp - WIDE_S) + 1] = __float_as_int(next_tmin); }
+                                sp++;
+                            }
+                            next_ref = ref[k]; next_tmin = tm[k];
+                        }
                     }
                 }
-                if (next_ref == WIDE_EMPTY) pop_next();
-                else if (next_ref >= 0) cur = next_ref;
-                else { const int info = ~next_ref; tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
+                if (next_ref != WIDE_EMPTY) take(next_ref);
             }
-            }
+            pop_loop();                                                     // lanes whose visit left them empty-handed
+        }
+#ifdef CL2_WALK_HISTO
+        if (active && wlane && tri_end - tri_i > 0 && tri_end - tri_i != h_tri_before) atomicAdd(&g_walk_histo[4][tri_end - tri_i], 1ull);   // a leaf was entered
+#endif
+
+        // ---- the triangles of the lane's leaf, a pair per round: ray_triangle_intersect (trace.metal:117-142) without early
+        // exits, one predicated update; the second of the pair sees the first one's best_t, as in the reference's loop ----
 #pragma unroll
-            for (int rep = 0; rep < (TWO_TRIS ? WIDE_TRI_REPS : 1); rep++)
-            if (tri_i < tri_end && (rep == 0 || wlane)) {
+        for (int rep = 0; rep < (TWO_TRIS ? WIDE_TRI_REPS : 1); rep++) {
+            const bool has = active && tri_i < tri_end;
+            if (!__any(has)) break;
+            if (has) {
+#ifdef CL2_WALK_HISTO
+                if (rep == 0) h_t0 = true; else h_t1 = true;
+#endif
                 const int i0 = tri_i;
-                const bool two = TWO_TRIS && i0 + 1 < tri_end;
-                const int i1 = two ? i0 + 1 : i0;
+                const int i1 = (TWO_TRIS && i0 + 1 < tri_end) ? i0 + 1 : i0;
                 tri_i = i1 + 1;
-                float4 a0, a1, a2, c0, c1, c2;
-                a0 = w.tris[3 * i0]; a1 = w.tris[3 * i0 + 1]; a2 = w.tris[3 * i0 + 2];
-                if (TWO_TRIS) { c0 = w.tris[3 * i1]; c1 = w.tris[3 * i1 + 1]; c2 = w.tris[3 * i1 + 2]; }
-                if (COUNT) n_tri += two ? 2 : 1;
-                tri_test(o, d, a0, a1, a2, i0, best);
-                if (TWO_TRIS && two) tri_test(o, d, c0, c1, c2, i1, best);
-            }
-            if (tri_i >= tri_end && (wlane ? (cur < 0 && sp == 0) : node >= n_nodes)) {
-                src.store(key, best);
-                active = false;
+                const float4* __restrict__ ta = w.tris + (size_t)3 * i0;
+                const float4* __restrict__ tb = w.tris + (size_t)3 * i1;
+                const float4 a0 = ta[0], a1 = ta[1], a2 = ta[2];
+                float4 c0, c1, c2;
+                if (TWO_TRIS) { c0 = tb[0]; c1 = tb[1]; c2 = tb[2]; }
+                auto test = [&](const float4& p0, const float4& p1, const float4& p2, int index) {
+                    const V3 e1 = v3(p1), e2 = v3(p2);
+                    const V3 h = cross(d, e2);
+                    const float f = rcp_exact(dot(e1, h));
+                    const V3 sv = o - v3(p0);
+                    const float u = f * dot(sv, h);
+                    const V3 q = cross(sv, e1);
+                    const float v = f * dot(d, q);
+                    const float t = f * dot(e2, q);
+                    const bool ok = !(u < 0 || u > 1) && !(v < 0 || u + v > 1) && (t > DELTA_F && t < best.t);
+                    best.tri = ok ? index : best.tri;
+                    best.t = ok ? t : best.t;
+                    best.u = ok ? u : best.u;
+                    best.v = ok ? v : best.v;
+                };
+                test(a0, a1, a2, i0);
+                if (TWO_TRIS) test(c0, c1, c2, i1);
             }
         }
+        // ---- retire: nothing in hand, nothing on the stack ----
+        if (active && tri_i >= tri_end && (wlane ? (cur < 0 && sp == 0) : node >= n_nodes)) {
+            src.store(key, best);
+            active = false;
+        }
+#ifdef CL2_WALK_HISTO
+        {
+            const int a = __popcll(__ballot(h_node)), bb = __popcll(__ballot(h_t0)), c = __popcll(__ballot(h_t1)), dd = __popcll(__ballot(!h_node && !h_t0));
+            int spmax = active ? sp : 0;
+            for (int off = 32; off > 0; off >>= 1) { const int other = __shfl_xor(spmax, off); spmax = other > spmax ? other : spmax; }
+            if (lane == 0) {
+                atomicAdd(&g_walk_histo[0][a], 1ull); atomicAdd(&g_walk_histo[1][bb], 1ull);
+                atomicAdd(&g_walk_histo[2][c], 1ull); atomicAdd(&g_walk_histo[3][dd], 1ull);
+                atomicAdd(&g_walk_histo[5][spmax > 64 ? 64 : spmax], 1ull);
+            }
+        }
+#endif
     }
 }
 

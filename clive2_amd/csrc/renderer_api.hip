@@ -340,8 +340,12 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
     // and pops went to the global overflow array inside the pass.  ms per sample, same box: glass 9.23 -> 8.81 (7 + 32) / 8.86
     // (7 + 64), blob 12.17 -> 11.51 / 11.57, 1M triangles 27.28 (7 + 32) / 26.48 (7 + 64) / 26.65 (8 + 64) / 26.53 (7 + 96);
     // on the small trees 8 + 64 and 6 + 96 lose: 9.25 / 9.28
-    w.stack_lds = sflag ? std::min(sflag, WIDE_STACK_LDS) : 7;
-    w.n_lds_nodes = std::min(r->n_wide, 32 * (wflag ? wflag : 2));
+    // round 4: WIDE_STACK_LDS (8) entries, a compile-time constant (shift-addressed), and NO window by default: 16 KB per
+    // workgroup, 8 workgroups per CU.  The window's lanes read LDS in a branch of their own (the per-lane pointer select of
+    // round 3 made every node fetch a flat load); debug_flags bits 20-23 ask for one, in units of 32 wide nodes.
+    (void)sflag;
+    w.stack_lds = WIDE_STACK_LDS;
+    w.n_lds_nodes = std::min(r->n_wide, 32 * wflag);
     // never more than the 64 KB a workgroup may ask for: the window gives way, the stack entries are needed
     w.n_lds_nodes = std::min<int>(w.n_lds_nodes, (int)(((size_t)64 * 1024 - (size_t)w.stack_lds * BLOCK * 8) / 128));
     const size_t lds = (size_t)w.stack_lds * BLOCK * 8 + (size_t)w.n_lds_nodes * 128;
@@ -896,7 +900,9 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
                 int ref[4];
                 for (int k = 0; k < 4; k++) {
                     ref[k] = WIDE_EMPTY;
-                    for (int c = 0; c < 6; c++) v[c][k] = 0.0f;
+                    // an empty slot holds a box at +inf: for a ray with finite 1/d its slab test gives tmin = +inf or tmax = -inf,
+                    // so `tmin <= tmax && tmin < best_t` fails without the walk looking at the reference (bvh_wide.hpp)
+                    for (int c = 0; c < 6; c++) v[c][k] = std::numeric_limits<float>::infinity();
                     if (k >= n) continue;
                     const BoxRec& b = boxes[sl[k]];
                     for (int c = 0; c < 3; c++) { v[c][k] = b.min[c]; v[3 + c][k] = b.max[c]; }
@@ -1690,6 +1696,17 @@ int cl2_set_subpath_gather(cl2_renderer* r, int lanes, int wait_steps) {
     r->gather_wait = wait_steps ? wait_steps : 48;
     return CL2_OK;
 }
+#ifdef CL2_WALK_HISTO
+/* instrumentation build only: read (and clear) the pass statistics of the wide walk, 6 x 65 counters */
+int cl2_walk_histo(cl2_renderer* r, unsigned long long* out) {
+    if (!r || !out) return CL2_E_INVALID;
+    TRY(drain(r));
+    HIP_TRY(r, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_histo), sizeof(unsigned long long) * 6 * 65));
+    std::vector<unsigned long long> z(6 * 65, 0ull);
+    HIP_TRY(r, hipMemcpyToSymbol(HIP_SYMBOL(g_walk_histo), z.data(), sizeof(unsigned long long) * 6 * 65));
+    return CL2_OK;
+}
+#endif
 int cl2_set_counting(cl2_renderer* r, int on) { if (!r) return CL2_E_INVALID; r->counting = on != 0; return CL2_OK; }
 
 int cl2_read_counters(cl2_renderer* r, cl2_counters* out) {
