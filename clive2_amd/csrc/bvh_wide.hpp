@@ -29,7 +29,10 @@
 namespace cl2 {
 
 constexpr int WIDE_EMPTY = (int)0x80000000;
-constexpr int WIDE_STACK_LDS = 8;
+#ifndef CL2_WIDE_STACK_LDS
+#define CL2_WIDE_STACK_LDS 8
+#endif
+constexpr int WIDE_STACK_LDS = CL2_WIDE_STACK_LDS;
 // Triangle pairs a lane in a leaf tests per pass.  The pass -- its refill check, its node block for the other lanes, its
 // bookkeeping, its dependent fetch -- is the unit of cost of the persistent walks, so a leaf of three or four
 // triangles should not take two of them: a second pair in the same pass (fetched after the first is tested) took the
@@ -82,10 +85,11 @@ struct WideView {
 constexpr int WIDE_NT = 256;                  // threads per workgroup of the wide launches (BLOCK)
 constexpr int WIDE_S = WIDE_STACK_LDS;        // stack entries per lane in LDS
 
-template <bool COUNT, bool TWO_TRIS, class Source>
-__device__ __forceinline__ void traverse_wide_persistent(const WideView& w, const BvhView& b, unsigned n, unsigned* work_counter, const Source& src,
-                                                         unsigned& n_box, unsigned& n_tri) {
-    static_assert(!COUNT, "the node-test tallies are defined by the binary walk");
+// TRI_REPS: triangle pairs a lane in a leaf tests per pass (WIDE_TRI_REPS = 2 while the tree is cache-resident; 1 when it streams
+// from memory: round 4, same box, 1M triangles: connection launch 11.2 -> 10.7 ms, sample 22.3 -> 21.3 ms).
+template <int TRI_REPS, class Source>
+__device__ __forceinline__ void traverse_wide_persistent(const WideView& w, const BvhView& b, unsigned n, unsigned* work_counter, const Source& src) {
+    constexpr bool TWO_TRIS = true;
     extern __shared__ float4 cl2_tree_lds[];
     const int tid = threadIdx.x;
     constexpr int NT = WIDE_NT;
@@ -266,7 +270,7 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
         // ---- the triangles of the lane's leaf, a pair per round: ray_triangle_intersect (trace.metal:117-142) without early
         // exits, one predicated update; the second of the pair sees the first one's best_t, as in the reference's loop ----
 #pragma unroll
-        for (int rep = 0; rep < (TWO_TRIS ? WIDE_TRI_REPS : 1); rep++) {
+        for (int rep = 0; rep < TRI_REPS; rep++) {
             const bool has = active && tri_i < tri_end;
             if (!__any(has)) break;
             if (has) {

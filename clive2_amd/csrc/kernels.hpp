@@ -311,12 +311,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(78))) void k_
 }
 
 // The same launch shape over the 4-wide collapse of the tree (bvh_wide.hpp): exact, half the dependent fetches.
-template <bool TWO_TRIS, class Source>
+template <int TRI_REPS, class Source>
 __global__ __launch_bounds__(BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) void k_traverse_wide(WideView wide, BvhView bvh, const unsigned* __restrict__ count,
                                                         unsigned* __restrict__ work_counter, Source src, Stats* stats, int is_conn) {
     const unsigned n = *count;
-    unsigned nb = 0, nt = 0;
-    traverse_wide_persistent<false, TWO_TRIS>(wide, bvh, n, work_counter, src, nb, nt);
+    traverse_wide_persistent<TRI_REPS>(wide, bvh, n, work_counter, src);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&stats->rays, (unsigned long long)n);
         if (is_conn) atomicAdd(&stats->conn_rays, (unsigned long long)n);

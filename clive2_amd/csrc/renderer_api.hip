@@ -274,9 +274,11 @@ inline bool whole_subpaths(const cl2_renderer* r) {
 // Two triangles per step of the persistent walk while the tree is cache-resident (the step is then
 // issue-bound and fewer, fatter steps win: glass +5 %, blob +4 %); one when it streams from memory
 // (1M triangles: two cost 3 %).  debug_flags bit 12 inverts the choice (tests run both forms).
+inline bool two_tris_per_step_plain(const cl2_renderer* r) {      // the size rule itself: the tree is cache-resident (<= 16 MB)
+    return (size_t)r->bvh.n_nodes * 32 + (size_t)r->bvh.n_tris * 48 <= ((size_t)16 << 20);
+}
 inline bool two_tris_per_step(const cl2_renderer* r) {
-    const size_t bytes = (size_t)r->bvh.n_nodes * 32 + (size_t)r->bvh.n_tris * 48;
-    const bool two = bytes <= ((size_t)16 << 20);
+    const bool two = two_tris_per_step_plain(r);
     return ((r->debug_flags >> 12) & 1) ? !two : two;
 }
 inline int effective_levels(const cl2_renderer* r) {
@@ -340,20 +342,28 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
     // and pops went to the global overflow array inside the pass.  ms per sample, same box: glass 9.23 -> 8.81 (7 + 32) / 8.86
     // (7 + 64), blob 12.17 -> 11.51 / 11.57, 1M triangles 27.28 (7 + 32) / 26.48 (7 + 64) / 26.65 (8 + 64) / 26.53 (7 + 96);
     // on the small trees 8 + 64 and 6 + 96 lose: 9.25 / 9.28
-    // round 4: WIDE_STACK_LDS (8) entries, a compile-time constant (shift-addressed), and NO window by default: 16 KB per
-    // workgroup, 8 workgroups per CU.  The window's lanes read LDS in a branch of their own (the per-lane pointer select of
-    // round 3 made every node fetch a flat load); debug_flags bits 20-23 ask for one, in units of 32 wide nodes.
+    // round 4: WIDE_STACK_LDS (8) entries, a compile-time constant (shift-addressed).  The window's lanes read LDS in a
+    // branch of their own (the per-lane pointer select of round 3 made EVERY node fetch a flat load).  Same-box A/B of the
+    // rewritten walk, ms (connection launch alone | sample), stack entries + window nodes:
+    //   glass     8+0 3.28 | 8.17   8+32 3.09 | 7.90   7+64 3.19 | 7.79   8+64 3.35 | 7.98   6+64 3.11 | 7.91   6+128 3.68 | 8.68
+    //   blob      8+0 4.18 | 10.30  8+32 3.90 | 9.95   7+64 4.02 | 9.97   8+64 4.15 | 10.15
+    //   interior  8+0 12.0 | 24.2   8+32 11.2 | 22.8   7+64 11.2 | 23.3   8+64 11.2 | 22.3; one triangle pair per pass: 8+64 10.7 | 21.3
+    // so: 32 nodes (20 KB per workgroup: 8 workgroups per CU) and two pairs per pass while the tree is cache-resident, 64
+    // nodes and one pair when it streams from memory.  debug_flags bits 20-23 override the window (units of 32 nodes, 15 = none).
     (void)sflag;
+    const bool streams_from_memory = !two_tris_per_step_plain(r);
     w.stack_lds = WIDE_STACK_LDS;
-    w.n_lds_nodes = std::min(r->n_wide, 32 * wflag);
+    w.n_lds_nodes = std::min(r->n_wide, wflag == 15 ? 0 : (wflag ? 32 * wflag : (streams_from_memory ? 64 : 32)));
     // never more than the 64 KB a workgroup may ask for: the window gives way, the stack entries are needed
     w.n_lds_nodes = std::min<int>(w.n_lds_nodes, (int)(((size_t)64 * 1024 - (size_t)w.stack_lds * BLOCK * 8) / 128));
     const size_t lds = (size_t)w.stack_lds * BLOCK * 8 + (size_t)w.n_lds_nodes * 128;
     // the binary records (lanes whose ray has a non-finite 1/d) come through the caches: no window for them
     BvhView b = r->bvh;
     b.n_lds_nodes = 0; b.lds_tris = 0; b.n_fast_nodes = 0;
-    // always two triangle pairs per pass: the pass, not the fetch, is the unit of cost of this walk (bvh_wide.hpp)
-    hipLaunchKernelGGL((k_traverse_wide<true, Source>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn);
+    if (streams_from_memory)
+        hipLaunchKernelGGL((k_traverse_wide<1, Source>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn);
+    else
+        hipLaunchKernelGGL((k_traverse_wide<WIDE_TRI_REPS, Source>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn);
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;
 }
@@ -1125,10 +1135,20 @@ int cl2_set_sample_streams(cl2_renderer* r, int streams) {
     HIP_TRY(r, hipSetDevice(r->device));
     TRY(drain(r));
     if (streams == r->streams) return CL2_OK;
+    const int before = r->streams;
     free_pixel_state(r);
     r->streams = streams; r->B = streams * r->FB; r->export_stream = 0;
     r->paths_share = 0; r->levels_auto = 0;                       // launch sizes changed: measure the organisation again
-    return alloc_pixel_state(r);
+    int rc = alloc_pixel_state(r);
+    if (rc != CL2_OK) {
+        // not enough device memory for that many streams (about 3.4 KB per entry): the handle goes back to what it had
+        const std::string why = r->err;
+        free_pixel_state(r);
+        r->streams = before; r->B = before * r->FB;
+        if (alloc_pixel_state(r) != CL2_OK) { r->scene_ok = false; return fail(r, rc, why + "; and the previous stream count could not be restored: the handle is unusable"); }
+        return fail(r, rc, why + " (sample streams unchanged; seeds were reset)");
+    }
+    return CL2_OK;
 }
 int cl2_get_sample_streams(const cl2_renderer* r) { return r ? r->streams : CL2_E_INVALID; }
 /* the stream that cl2_export_* / cl2_import_sample_images address (one frame's worth of records each) */
