@@ -98,7 +98,7 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def static_pmc(scene, W, H):
+def static_pmc(scene, W, H, streams=1):
     """Per-launch PMC figures of the connection-ray traversal kernel from profiles/r<NN>_pmc_<scene>.json
     (tools/profile_round.sh + tools/profile_summaries.py: rocprofv3 --pmc passes of this same command), or
     None when there is no summary for this scene / frame size, or the kernel sources have changed since
@@ -109,7 +109,7 @@ def static_pmc(scene, W, H):
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if d.get("sources_sha") != sha or (d.get("width"), d.get("height")) != (W, H):
+        if d.get("sources_sha") != sha or (d.get("width"), d.get("height")) != (W, H) or d.get("sample_streams", 1) != streams:
             continue
         row = d.get("kernels", {}).get(d.get("conn_traversal_kernel"))
         if row:
@@ -117,7 +117,18 @@ def static_pmc(scene, W, H):
     return None
 
 
+_SCENES = {}
+
+
 def build_scene(name, W, H, builder=None):
+    """(scene, description) of a bench workload; built once per process (the K = 8 and K = 1 legs share it)."""
+    key = (name, W, H, builder)
+    if key not in _SCENES:
+        _SCENES[key] = _build_scene(name, W, H, builder)
+    return _SCENES[key]
+
+
+def _build_scene(name, W, H, builder=None):
     import numpy as np
     import clive2_amd as c2
     if name == "cornell":
@@ -146,20 +157,36 @@ def build_scene(name, W, H, builder=None):
     return s, desc + f", {len(s.triangles)} tris / {len(s.boxes)} boxes"
 
 
-def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world, with_comm):
+def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world, with_comm, streams=1):
     """Warm-up (tuner + counting pass), the timed region, a serial per-stage breakdown.  `steps` = samples THIS
-    rank renders inside the clock.  Returns the pieces of the JSON line that depend on the workload."""
+    rank renders inside the clock; with `streams` = K sample streams (cl2_set_sample_streams: K independent samples of the
+    frame per pass, one seed buffer each) that is ceil(steps / K) passes.  Returns the pieces of the JSON line that depend
+    on the workload."""
     import clive2_amd as c2  # noqa: F401
     from clive2_amd import _native
-    from clive2_amd.renderer import Renderer, make_seeds
+    from clive2_amd.renderer import Renderer, stream_seeds
     from clive2_amd.distributed import join_communicator
 
     scene, scene_desc = build_scene(scene_name, W, H)
     n_dev = max(_native.lib().cl2_device_count(), 1)
-    # a launcher may expose one GPU per rank (HIP_VISIBLE_DEVICES=<rank>): then the rank's GPU is device 0
-    r = Renderer(scene, seeds=make_seeds(W * H, rank=rank), device=local_rank % n_dev)
+    passes = max(1, -(-steps // streams))
+    steps = passes * streams                     # samples this rank renders inside the clock
+    # a launcher may expose one GPU per rank (HIP_VISIBLE_DEVICES=<rank>): then the rank's GPU is device 0.
+    # Seed buffers: stream k of rank r is buffer r * K + k of the job -- no two streams of the job share one
+    r = Renderer(scene, seeds=stream_seeds(W * H, streams, first_rank=rank * streams), device=local_rank % n_dev, streams=streams)
+    comm = None
     if with_comm:
         join_communicator(r, rank, world)        # untimed: communicator and its buffers exist before the clock starts
+        # what the COMMUNICATOR says (not the launcher's environment): rank count, and the PCI address of every rank's GPU,
+        # gathered as a sum of one-hot vectors through the library's own small all-reduce
+        info = r.comm_info()
+        addr = [0.0] * min(max(info["nranks"], 1), 16)
+        if info["rank"] < len(addr):
+            addr[info["rank"]] = float(info["pci_address"])
+        addr = r.allreduce_host(addr, op="sum")
+        comm = {"nranks": info["nranks"], "rank0_device": info["pci_bus_id"],
+                "devices": ["%04x:%02x:%02x.%x" % (int(a) >> 16, (int(a) >> 8) & 0xFF, (int(a) >> 3) & 0x1F, int(a) & 7) for a in addr],
+                "distinct_devices": len({int(a) for a in addr}), "launcher_world_size": world}
 
     def barrier():
         r.synchronize()
@@ -177,7 +204,7 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
     # cl2_tune, 1 / 42 real samples), then the counting pass that measures N_node / N_tri per ray
     tuned = r.tune()
     r.set_counting(True)
-    r.run_samples(max(warmup, 1))
+    r.run_samples(max(1, -(-max(warmup, 1) // streams)))
     cw = r.counters()
     n_node = cw["box_tests"] / max(cw["counted_rays"], 1)
     n_tri = cw["tri_tests"] / max(cw["counted_rays"], 1)
@@ -191,9 +218,11 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
 
     barrier()
     t0 = time.perf_counter()
-    r.run_samples(steps)
+    r.run_samples(passes)
+    t_reduce = time.perf_counter()
     if with_comm:
-        r.reduce_accumulators()
+        r.reduce_accumulators()              # returns when the collective is complete on this rank
+    t_reduce = time.perf_counter() - t_reduce
     barrier()
     dt = time.perf_counter() - t0
 
@@ -204,17 +233,20 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
     # untimed: per-stage breakdown (HIP events around every launch) over a few more samples, in serial
     # order on one stream -- with the sample pipeline on, spans of the two streams overlap and a
     # stage's span includes whatever ran beside it
-    n_break = max(1, min(steps, 8))
+    n_break_passes = max(1, min(passes, max(1, 8 // streams)))
+    n_break = n_break_passes * streams
     r.reset_counters()
     r.set_profiling(2)
     r.set_pipelining(0)
-    r.run_samples(n_break)
+    r.run_samples(n_break_passes)
     cb = r.counters()
     r.set_profiling(0)
     r.set_pipelining(args.pipelining)
     if with_comm:
         rays_total, steps_total = r.allreduce_host([float(rays_local), float(steps)], op="sum")
-        dt = r.allreduce_host([dt], op="max")[0]
+        dt, t_reduce_max = r.allreduce_host([dt, t_reduce], op="max")
+        comm["allreduce_ms"] = round(t_reduce_max * 1e3, 3)          # slowest rank's wait for the 8*W*H-float all-reduce (includes waiting for the last rank to arrive)
+        comm["allreduce_bytes"] = 8 * W * H * 4
     else:
         rays_total, steps_total = float(rays_local), float(steps)
 
@@ -232,12 +264,13 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
             else "k_traverse_conn"
         b_ray = 48.0 + 32.0 * n_node + 36.0 * n_tri
         k_ms, k_rays, k_launches = c["ms_traverse_conn"], c["rays_traverse_conn"], max(c["launches_traverse_conn"], 1)
+        # (a launch of a handle with K sample streams carries the connection rays of K samples)
         avg_ms = k_ms / k_launches
         alone_ms = cb["ms_traverse_conn"] / max(cb["launches_traverse_conn"], 1)
         rays_per_launch = k_rays / k_launches
         alg_gbs = rays_per_launch * b_ray / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         alg_gbs_alone = (cb["rays_traverse_conn"] / max(cb["launches_traverse_conn"], 1)) * b_ray / max(alone_ms * 1e-3, 1e-12) / 1e9
-        pmc = static_pmc(scene_name, W, H)
+        pmc = static_pmc(scene_name, W, H, streams)
         traffic = pmc.get("hbm_bytes") if pmc else None
         lanes = pmc.get("thread_cycles_per_valu_inst") if pmc else None     # average active lanes per VALU wave-instruction
         hbm = {"algorithmic_gbs": round(alg_gbs, 1), "algorithmic_gbs_launch_alone": round(alg_gbs_alone, 1),
@@ -270,8 +303,10 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
                     "frac": round(alg_gbs / peak, 4), "frac_launch_alone": round(alg_gbs_alone / peak, 4),
                     "tree_bytes": org["tree_bytes"], "hbm": hbm}
         roof.update(common)
+        roof["sample_streams"] = streams
         out = {"scene_desc": scene_desc, "rays_total": rays_total, "rays_local": rays_local, "dt": dt, "roofline": roof,
-               "steps_total": int(steps_total), "tuner_samples_in_warmup": tuned, "paths_share": org["paths_share"],
+               "steps_total": int(steps_total), "steps_rank": steps, "tuner_samples_in_warmup": tuned * streams, "paths_share": org["paths_share"],
+               "comm": comm, "sample_streams": streams,
                "stages": {k[3:]: round(cb[k] / n_break, 4) for k in cb if k.startswith("ms_")}}
     r.close()
     return out
@@ -434,6 +469,11 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mesh", action="store_true", help="skip the mesh workloads (config 3 and config 5 stand-ins) of the N=1 line")
+    ap.add_argument("--sample-streams", type=int, default=1,
+                    help="sample streams of the headline workload (K independent samples of the frame per pass, cl2_set_sample_streams); "
+                         "1 = the reference's single seed buffer per renderer")
+    ap.add_argument("--mesh-streams", type=int, default=8, help="sample streams of the mesh legs (their K = 1 figure is reported beside it)")
+    ap.add_argument("--strong-spp", type=int, default=1024, help="N > 1: total samples of the strong-scaling leg (config 4 stand-in, split over the ranks); 0 = skip")
     ap.add_argument("--mesh-steps", type=int, default=64)
     ap.add_argument("--hbm-steps", type=int, default=24)
     ap.add_argument("--debug-flags", type=int, default=0, help="launch-organisation switches (include/clive2_amd.h); results unchanged")
@@ -481,7 +521,23 @@ def main():
         my_steps = samples_for_rank(args.total_spp, rank, world)
     else:
         my_steps = args.steps
-    res = run_workload(args, args.scene, W, H, my_steps, args.warmup, rank, local_rank, world, with_comm=with_comm)
+    res = run_workload(args, args.scene, W, H, my_steps, args.warmup, rank, local_rank, world, with_comm=with_comm,
+                       streams=args.sample_streams)
+    strong_leg = None
+    if world > 1 and not strong and args.strong_spp > 0 and not args.no_mesh and args.scene == "cornell":
+        # the strong-scaling form on the same job: BASELINE config 4 -- a FIXED number of samples of the
+        # 82k-triangle scene split over the ranks, one all-reduce at the end
+        from clive2_amd.distributed import samples_for_rank
+        t_leg = time.perf_counter()
+        m = run_workload(args, "blob", W, H, samples_for_rank(args.strong_spp, rank, world), 2, rank, local_rank, world,
+                         with_comm=True, streams=args.mesh_streams)
+        if rank == 0:
+            strong_leg = {"workload": f"{m['scene_desc']} {W}x{H}, {args.strong_spp} spp in all, split over {world} GPUs "
+                                      f"({m['steps_rank']} on rank 0, {args.mesh_streams} sample streams per GPU)",
+                          "scaling": "strong", "samples_rendered_all_ranks": m["steps_total"], "seconds": round(m["dt"], 4),
+                          "value": round(m["rays_total"] / m["dt"] / 1e6, 2), "unit": "Mrays/s",
+                          "ms_per_sample_whole_job": round(m["dt"] / max(m["steps_total"], 1) * 1e3, 4),
+                          "comm": m["comm"], "leg_wall_s": round(time.perf_counter() - t_leg, 1)}
 
     if rank == 0:
         steps_out = args.total_spp if strong else args.steps
@@ -491,7 +547,7 @@ def main():
             "unit": "Mrays/s",
             "n_gpus": world, "steps": steps_out, "warmup": args.warmup,
             # weak: every rank renders `steps` samples side by side; strong: `steps` samples in all, split over the ranks
-            "ms_per_step": round(res["dt"] / steps_out * 1e3, 3),
+            "ms_per_step": round(res["dt"] / (args.total_spp if strong else res["steps_rank"]) * 1e3, 3),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{res['scene_desc']} {W}x{H}, BDPT{' diffuse-only' if args.scene == 'cornell' else ''}, "
@@ -499,24 +555,39 @@ def main():
                        "width": W, "height": H,
                        "rays_per_pixel_sample": round(res["rays_total"] / (res["steps_total"] * W * H), 3),
                        "samples_rendered_all_ranks": res["steps_total"],
+                       "sample_streams": res["sample_streams"],
                        "parallelism": f"sample-split x{world}, one in-place RCCL all-reduce of the accumulators"
                                       if with_comm else "one GPU (no collective)"},
             "roofline": res["roofline"],
             "stage_ms_per_step_serial": res["stages"],
         }
+        if res["comm"]:
+            # what RCCL itself reported: `nranks` ranks on `distinct_devices` different GPUs (PCI addresses of all ranks)
+            out["comm"] = res["comm"]
+        if strong_leg:
+            out["strong_scaling"] = strong_leg
         if world == 1 and not args.no_mesh and args.scene == "cornell":
             # two more workloads on the same line, where the tree is read through the caches and the bytes formula is a
             # memory statement: config 3 (1,781 boxes / 5,136 triangles: L2-resident -> bound "l2") and config 5 (338 k
             # boxes / 1 M triangles, 155 MB -> bound "hbm").  Their stage-share tuner runs in the warm-up (cl2_tune).
+            # Each leg runs with --mesh-streams sample streams (every launch then carries K samples' rays: a per-level subpath
+            # launch of ONE 1080p sample is 2 M rays on 524 k resident lanes and all tail) and once more with the reference's
+            # single seed buffer (K = 1), reported beside it.
             for key, name, n_steps in (("roofline_mesh", "glass", args.mesh_steps), ("roofline_hbm", "interior", args.hbm_steps)):
                 t_setup = time.perf_counter()
-                m = run_workload(args, name, W, H, n_steps, 2, 0, local_rank, 1, with_comm=False)
-                out[key] = dict(m["roofline"], workload=f"{m['scene_desc']} {W}x{H}, {n_steps} spp",
+                m = run_workload(args, name, W, H, n_steps, 2, 0, local_rank, 1, with_comm=False, streams=args.mesh_streams)
+                out[key] = dict(m["roofline"], workload=f"{m['scene_desc']} {W}x{H}, {m['steps_rank']} spp in {args.mesh_streams} sample streams",
                                 mrays_per_s=round(m["rays_total"] / m["dt"] / 1e6, 2),
-                                ms_per_step=round(m["dt"] / n_steps * 1e3, 3),
+                                ms_per_step=round(m["dt"] / m["steps_rank"] * 1e3, 3),
                                 tuner_samples_in_warmup=m["tuner_samples_in_warmup"], paths_share=m["paths_share"],
-                                leg_wall_s=round(time.perf_counter() - t_setup, 1),
                                 stage_ms_per_step_serial=m["stages"])
+                if args.mesh_streams != 1:
+                    m1 = run_workload(args, name, W, H, max(8, n_steps // 2), 2, 0, local_rank, 1, with_comm=False, streams=1)
+                    out[key]["one_stream"] = {"sample_streams": 1, "mrays_per_s": round(m1["rays_total"] / m1["dt"] / 1e6, 2),
+                                              "ms_per_step": round(m1["dt"] / m1["steps_rank"] * 1e3, 3), "steps": m1["steps_rank"],
+                                              "frac": m1["roofline"]["frac"], "frac_launch_alone": m1["roofline"]["frac_launch_alone"],
+                                              "avg_launch_ms": m1["roofline"]["avg_launch_ms"], "paths_share": m1["paths_share"]}
+                out[key]["leg_wall_s"] = round(time.perf_counter() - t_setup, 1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_width, args.cpu_height, args.cpu_samples)
         sys.stdout.flush()

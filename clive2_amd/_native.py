@@ -62,6 +62,11 @@ class Organisation(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class CommInfo(C.Structure):
+    _fields_ = [("nranks", C.c_int32), ("rank", C.c_int32), ("comm_device", C.c_int32), ("device_ordinal", C.c_int32),
+                ("pci_address", C.c_int64), ("pci_bus_id", C.c_char * 32)]
+
+
 EXPORTS = [
     "cl2_create", "cl2_destroy", "cl2_last_error", "cl2_abi_version", "cl2_build_bvh", "cl2_build_bvh_gpu", "cl2_set_create_error", "cl2_upload_scene", "cl2_set_seeds",
     "cl2_get_seeds", "cl2_make_light_rays", "cl2_make_camera_rays", "cl2_trace_light_rays",
@@ -73,7 +78,7 @@ EXPORTS = [
     "cl2_reset_counters", "cl2_selftest_exact_math", "cl2_export_rays", "cl2_export_paths", "cl2_export_aggregators",
     "cl2_export_sample_images", "cl2_probe_traverse", "cl2_probe_math", "cl2_probe_bounce",
     "cl2_tune", "cl2_set_subpath_gather", "cl2_comm_abort", "cl2_tone_log_sum", "cl2_tone_map",
-    "cl2_set_sample_streams", "cl2_get_sample_streams", "cl2_set_export_stream",
+    "cl2_set_sample_streams", "cl2_get_sample_streams", "cl2_set_export_stream", "cl2_comm_info",
 ]
 
 
@@ -133,6 +138,7 @@ def lib(variant=None):
         L.cl2_set_sample_streams.argtypes = [C.c_void_p, C.c_int]
         L.cl2_get_sample_streams.argtypes = [C.c_void_p]
         L.cl2_set_export_stream.argtypes = [C.c_void_p, C.c_int]
+        L.cl2_comm_info.argtypes = [C.c_void_p, C.POINTER(CommInfo)]
         L.cl2_tone_log_sum.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
         L.cl2_tone_map.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_size_t]
         for name in ("cl2_reduce_accumulators", "cl2_comm_destroy", "cl2_comm_abort", "cl2_synchronize"):

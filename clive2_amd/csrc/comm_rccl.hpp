@@ -27,6 +27,9 @@ struct RcclApi {
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
     std::string error;
 };
 
@@ -51,6 +54,9 @@ inline RcclApi* rccl_api(std::string& why) {
         CL2_SYM(AllReduce, "ncclAllReduce");
         CL2_SYM(CommGetAsyncError, "ncclCommGetAsyncError");
         CL2_SYM(GetErrorString, "ncclGetErrorString");
+        CL2_SYM(CommCount, "ncclCommCount");
+        CL2_SYM(CommUserRank, "ncclCommUserRank");
+        CL2_SYM(CommCuDevice, "ncclCommCuDevice");
 #undef CL2_SYM
     });
     if (!api.error.empty()) { why = api.error; return nullptr; }

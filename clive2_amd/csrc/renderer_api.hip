@@ -1576,6 +1576,32 @@ int cl2_comm_allreduce_f64(cl2_renderer* r, double* values, int n, int op) {
     return CL2_OK;
 }
 
+/* What the COMMUNICATOR says about itself (not what the launcher's environment says): ncclCommCount, ncclCommUserRank,
+ * ncclCommCuDevice, and the PCI address of this rank's GPU as one integer, domain << 16 | bus << 8 | device << 3 | function
+ * (hipDeviceGetPCIBusId).  A job line that lists nranks distinct addresses shows that RCCL saw that many GPUs. */
+int cl2_comm_info(cl2_renderer* r, cl2_comm_info_t* out) {
+    if (!r || !out) return CL2_E_INVALID;
+    std::memset(out, 0, sizeof *out);
+    out->device_ordinal = r->device;
+    HIP_TRY(r, hipSetDevice(r->device));
+    char bus[32] = {0};
+    HIP_TRY(r, hipDeviceGetPCIBusId(bus, (int)sizeof bus, r->device));
+    unsigned dom = 0, b = 0, dev = 0, fn = 0;
+    if (std::sscanf(bus, "%x:%x:%x.%x", &dom, &b, &dev, &fn) >= 3)
+        out->pci_address = ((int64_t)dom << 16) | ((int64_t)b << 8) | ((int64_t)dev << 3) | (int64_t)fn;
+    std::snprintf(out->pci_bus_id, sizeof out->pci_bus_id, "%s", bus);
+    if (!r->comm) return CL2_OK;                       // nranks = 0: no communicator
+    std::string why;
+    RcclApi* api = rccl_api(why);
+    if (!api) return fail(r, CL2_E_COMM, why);
+    int n = 0, rank = -1, cudev = -1;
+    RCCL_TRY(r, api, api->CommCount(r->comm, &n));
+    RCCL_TRY(r, api, api->CommUserRank(r->comm, &rank));
+    RCCL_TRY(r, api, api->CommCuDevice(r->comm, &cudev));
+    out->nranks = n; out->rank = rank; out->comm_device = cudev;
+    return CL2_OK;
+}
+
 /* The host's way of saying "this rank failed, do not wait for anybody": the communicator is torn down with
  * ncclCommAbort at once, so peers blocked in a collective with this rank see an error or their own deadline
  * instead of waiting for a rank that is about to exit.  Harmless without a communicator. */

@@ -277,6 +277,14 @@ class Renderer:
         self._check(self._L.cl2_comm_allreduce_f64(self._h, v, len(values), {"sum": 0, "max": 1}[op]), "cl2_comm_allreduce_f64")
         return list(v)
 
+    def comm_info(self):
+        """What the communicator says about itself (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) and the PCI address
+        of this handle's GPU; `nranks` is 0 without a communicator."""
+        info = _native.CommInfo()
+        self._check(self._L.cl2_comm_info(self._h, C.byref(info)), "cl2_comm_info")
+        return {"nranks": info.nranks, "rank": info.rank, "comm_device": info.comm_device, "device_ordinal": info.device_ordinal,
+                "pci_address": info.pci_address, "pci_bus_id": info.pci_bus_id.decode()}
+
     def comm_destroy(self):
         self._check(self._L.cl2_comm_destroy(self._h), "cl2_comm_destroy")
 

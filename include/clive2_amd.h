@@ -224,6 +224,18 @@ int cl2_comm_destroy(cl2_renderer* r);
  * a failed state. */
 int cl2_comm_abort(cl2_renderer* r);
 
+/* What the communicator reports about itself (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) and which GPU this
+ * handle sits on (hipDeviceGetPCIBusId): the evidence that an N-rank job really spanned N devices (bench.py gathers the
+ * addresses of all ranks into its JSON line).  Without a communicator nranks is 0 and the device fields are still filled. */
+typedef struct {
+    int32_t nranks, rank;           /* from the communicator; 0 / 0 without one */
+    int32_t comm_device;            /* the device ordinal RCCL bound the communicator to */
+    int32_t device_ordinal;         /* the ordinal this handle was created on */
+    int64_t pci_address;            /* domain << 16 | bus << 8 | device << 3 | function */
+    char pci_bus_id[32];            /* "0000:c1:00.0" */
+} cl2_comm_info_t;
+int cl2_comm_info(cl2_renderer* r, cl2_comm_info_t* out);
+
 /* How the library organises the launches for the uploaded scene (all organisations give identical results;
  * this is what the automatic choices of cl2_set_traversal_mode / _levels_per_launch / _pipelining came to). */
 typedef struct {

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run ON THE GPU BOX from the repo root: rocprofv3 PMC passes (counters only + kernel trace, each set in its own pass) of
+# tools/one_streams.py:   bash tools/pmc_streams.sh <scene> <K> <passes> <tag>
+set -e
+export TMPDIR=/tmp
+SCENE=$1; K=$2; N=$3; TAG=$4
+OUT=gpurun_out
+export ONE_TUNE=0
+pass() {
+    local name=$1; shift
+    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$name -o run -- python3 tools/one_streams.py $SCENE $K $N > $OUT/pmc_${TAG}_$name.log 2>&1
+    echo "$name pass done"
+}
+pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
+pass tcc TCC_HIT_sum TCC_MISS_sum SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
