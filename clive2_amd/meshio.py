@@ -1,10 +1,20 @@
-"""Minimal PLY / OBJ readers (stand-ins for the absent `plyfile` / `objloader` modules the
-reference calls at `src/load.py:80-82,90-94`) and matching writers used by the tests.
+"""PLY / OBJ readers (stand-ins for the absent `plyfile` / `objloader` modules the reference calls at
+`src/load.py:76-96`) and matching writers used by the tests.
 
-PLY: ascii or binary_little_endian; `vertex` element with float32 x,y,z first (extra vertex
-properties are skipped), `face` element with one list property of 3 indices.
-OBJ: `v x y z` and triangular `f a[/..] b[/..] c[/..]` lines, 1-based (the reference takes
-`obj.face[:, 0] - 1`).
+What the reference takes from those libraries is small: `ply["vertex"]` as (n, 3) float32 coordinates and
+`ply["face"]["vertex_indices"]` as (m, 3) indices (`load.py:88-94`); `obj.vert` and the vertex index of every face corner,
+1-based (`load.py:80-82`).  The readers return exactly that -- (vertices, faces) with faces (m, 3) int32, 0-based -- for
+the files those libraries read:
+
+PLY   `format ascii | binary_little_endian | binary_big_endian 1.0`; any elements in any order; the `vertex` element's
+      x, y, z wherever they stand among its properties and whatever their scalar type (extra properties -- the Stanford
+      bunny's `confidence`, `intensity` -- are skipped; the reference's own `.view(np.float32).reshape(-1, 3)` only works
+      for a vertex element of exactly three float32, `load.py:90-92`); the `face` element's list property
+      `vertex_indices` / `vertex_index` with any count / index types.  Polygons are fan-triangulated (v0 vi vi+1).
+OBJ   `v x y z [w]`; `f` with corners `v`, `v/vt`, `v//vn`, `v/vt/vn`; negative (relative) indices; polygons
+      fan-triangulated; every other statement (vt, vn, o, g, s, usemtl, mtllib, comments) is ignored.
+Refused with a message that says what and where: truncated data, a face with fewer than three corners, an index outside
+the vertex array, a list property in the vertex element, unknown scalar types.
 """
 import numpy as np
 
@@ -12,6 +22,18 @@ _PLY_TYPES = {"char": "i1", "uchar": "u1", "short": "i2", "ushort": "u2", "int":
               "uint": "u4", "float": "f4", "double": "f8", "int8": "i1", "uint8": "u1",
               "int16": "i2", "uint16": "u2", "int32": "i4", "uint32": "u4",
               "float32": "f4", "float64": "f8"}
+_FACE_LISTS = ("vertex_indices", "vertex_index")
+
+
+def _ply_type(name, path):
+    if name not in _PLY_TYPES:
+        raise ValueError(f"{path}: unknown PLY scalar type '{name}'")
+    return _PLY_TYPES[name]
+
+
+def _fan(corners):
+    """(m, 3) triangles of polygons given as index lists: v0 vi vi+1."""
+    return [(c[0], c[i], c[i + 1]) for c in corners for i in range(1, len(c) - 1)]
 
 
 def read_ply(path):
@@ -23,46 +45,145 @@ def read_ply(path):
             line = fh.readline()
             if not line:
                 raise ValueError(f"{path}: truncated PLY header")
-            tok = line.decode("ascii").split()
-            if not tok or tok[0] == "comment":
+            tok = line.decode("ascii", errors="replace").split()
+            if not tok or tok[0] in ("comment", "obj_info"):
                 continue
             if tok[0] == "format":
                 fmt = tok[1]
             elif tok[0] == "element":
                 elements.append((tok[1], int(tok[2]), []))
             elif tok[0] == "property":
+                if not elements:
+                    raise ValueError(f"{path}: property before any element")
                 elements[-1][2].append(tok[1:])
             elif tok[0] == "end_header":
                 break
-        if fmt not in ("ascii", "binary_little_endian"):
-            raise NotImplementedError(f"{path}: PLY format {fmt}")
+        if fmt not in ("ascii", "binary_little_endian", "binary_big_endian"):
+            raise ValueError(f"{path}: PLY format '{fmt}' (expected ascii, binary_little_endian or binary_big_endian)")
+        order = ">" if fmt == "binary_big_endian" else "<"
         verts = faces = None
         for name, count, props in elements:
-            is_list = any(p[0] == "list" for p in props)
+            lists = [p for p in props if p[0] == "list"]
+            if name == "vertex" and lists:
+                raise ValueError(f"{path}: list property '{lists[0][-1]}' in the vertex element")
             if fmt == "ascii":
-                rows = [fh.readline().split() for _ in range(count)]
+                rows = []
+                for k in range(count):
+                    line = fh.readline()
+                    if not line:
+                        raise ValueError(f"{path}: element '{name}' ends after {k} of {count} rows")
+                    rows.append(line.split())
                 if name == "vertex":
-                    verts = np.array([r[:3] for r in rows], dtype=np.float32)
+                    verts = _vertex_columns(path, props, rows)
                 elif name == "face":
-                    faces = np.array([r[1:4] for r in rows], dtype=np.int32)
-            elif not is_list:
-                dt = np.dtype([(p[1], "<" + _PLY_TYPES[p[0]]) for p in props])
-                data = np.frombuffer(fh.read(dt.itemsize * count), dtype=dt)
+                    faces = _faces_from_rows(path, props, rows)
+                continue
+            if not lists:
+                dt = np.dtype([(p[1], order + _ply_type(p[0], path)) for p in props])
+                raw = fh.read(dt.itemsize * count)
+                if len(raw) != dt.itemsize * count:
+                    raise ValueError(f"{path}: element '{name}' is truncated ({len(raw)} of {dt.itemsize * count} bytes)")
                 if name == "vertex":
+                    data = np.frombuffer(raw, dtype=dt)
+                    for axis in "xyz":
+                        if axis not in dt.names:
+                            raise ValueError(f"{path}: the vertex element has no '{axis}' property")
                     verts = np.stack([data["x"], data["y"], data["z"]], axis=1).astype(np.float32)
-            else:
-                if len(props) != 1:
-                    raise NotImplementedError("PLY list element with extra properties")
-                cnt_t, idx_t = ("<" + _PLY_TYPES[t] for t in props[0][1:3])
-                dt = np.dtype([("n", cnt_t), ("v", idx_t, (3,))])
-                data = np.frombuffer(fh.read(dt.itemsize * count), dtype=dt)
-                if name == "face":
-                    if count and not np.all(data["n"] == 3):
-                        raise NotImplementedError("PLY with non-triangular faces")
-                    faces = data["v"].astype(np.int32)
+                continue
+            corners = _binary_list_element(path, fh, name, count, props, order)
+            if name == "face":
+                faces = corners
         if verts is None or faces is None:
-            raise ValueError(f"{path}: PLY needs vertex and face elements")
-        return verts, faces
+            raise ValueError(f"{path}: PLY needs a vertex and a face element")
+        faces = np.asarray(_fan(faces) if not isinstance(faces, np.ndarray) else faces, dtype=np.int64).reshape(-1, 3)
+        _check_indices(path, faces, len(verts))
+        return verts, faces.astype(np.int32)
+
+
+def _vertex_columns(path, props, rows):
+    names = [p[1] for p in props]
+    try:
+        cols = [names.index(a) for a in "xyz"]
+    except ValueError:
+        raise ValueError(f"{path}: the vertex element needs x, y and z properties (has {names})") from None
+    try:
+        return np.array([[r[c] for c in cols] for r in rows], dtype=np.float64).astype(np.float32).reshape(-1, 3)
+    except (IndexError, ValueError):
+        raise ValueError(f"{path}: malformed vertex row") from None
+
+
+def _faces_from_rows(path, props, rows):
+    """ASCII face rows: properties in order, the corner list among them."""
+    out = []
+    for k, r in enumerate(rows):
+        pos, corners = 0, None
+        try:
+            for p in props:
+                if p[0] == "list":
+                    n = int(r[pos])
+                    items = r[pos + 1:pos + 1 + n]
+                    if len(items) != n:
+                        raise IndexError
+                    pos += 1 + n
+                    if p[-1] in _FACE_LISTS:
+                        corners = [int(x) for x in items]
+                else:
+                    pos += 1
+        except (IndexError, ValueError):
+            raise ValueError(f"{path}: malformed face row {k}") from None
+        if corners is None:
+            raise ValueError(f"{path}: the face element has no vertex_indices list (properties: {[p[-1] for p in props]})")
+        if len(corners) < 3:
+            raise ValueError(f"{path}: face {k} has {len(corners)} corners")
+        out.append(corners)
+    return out
+
+
+def _binary_list_element(path, fh, name, count, props, order):
+    """An element with list properties.  Fast path: one list property and every row three items long (what the reference's
+    meshes are); otherwise row by row."""
+    if len(props) == 1 and count:
+        cnt_t, idx_t = (order + _ply_type(t, path) for t in props[0][1:3])
+        dt = np.dtype([("n", cnt_t), ("v", idx_t, (3,))])
+        start = fh.tell()
+        raw = fh.read(dt.itemsize * count)
+        if len(raw) == dt.itemsize * count:
+            data = np.frombuffer(raw, dtype=dt)
+            if np.all(data["n"] == 3):
+                return data["v"].astype(np.int64) if props[0][-1] in _FACE_LISTS else None
+        fh.seek(start)
+    out = []
+    for k in range(count):
+        corners = None
+        for p in props:
+            if p[0] == "list":
+                cnt_t, idx_t = (np.dtype(order + _ply_type(t, path)) for t in p[1:3])
+                raw = fh.read(cnt_t.itemsize)
+                if len(raw) != cnt_t.itemsize:
+                    raise ValueError(f"{path}: element '{name}' is truncated in row {k}")
+                n = int(np.frombuffer(raw, cnt_t)[0])
+                raw = fh.read(idx_t.itemsize * n)
+                if len(raw) != idx_t.itemsize * n:
+                    raise ValueError(f"{path}: element '{name}' is truncated in row {k}")
+                if p[-1] in _FACE_LISTS:
+                    corners = [int(x) for x in np.frombuffer(raw, idx_t)]
+            else:
+                t = np.dtype(order + _ply_type(p[0], path))
+                if len(fh.read(t.itemsize)) != t.itemsize:
+                    raise ValueError(f"{path}: element '{name}' is truncated in row {k}")
+        if name == "face":
+            if corners is None:
+                raise ValueError(f"{path}: the face element has no vertex_indices list")
+            if len(corners) < 3:
+                raise ValueError(f"{path}: face {k} has {len(corners)} corners")
+            out.append(corners)
+    return out
+
+
+def _check_indices(path, faces, n_vertices):
+    if faces.size and (faces.min() < 0 or faces.max() >= n_vertices):
+        bad = int(np.flatnonzero((faces < 0).any(axis=1) | (faces >= n_vertices).any(axis=1))[0])
+        raise ValueError(f"{path}: triangle {bad} refers to vertex {faces[bad].tolist()} of {n_vertices}")
 
 
 def write_ply(path, vertices, faces, binary=True):
@@ -89,17 +210,33 @@ def write_ply(path, vertices, faces, binary=True):
 def read_obj(path):
     verts, faces = [], []
     with open(path, "r") as fh:
-        for line in fh:
-            tok = line.split()
+        for lineno, line in enumerate(fh, 1):
+            tok = line.split("#", 1)[0].split()
             if not tok:
                 continue
             if tok[0] == "v":
-                verts.append([float(x) for x in tok[1:4]])
+                try:
+                    verts.append([float(x) for x in tok[1:4]])
+                    if len(verts[-1]) != 3:
+                        raise ValueError
+                except ValueError:
+                    raise ValueError(f"{path}:{lineno}: malformed vertex statement") from None
             elif tok[0] == "f":
-                if len(tok) != 4:
-                    raise NotImplementedError("OBJ with non-triangular faces")
-                faces.append([int(t.split("/")[0]) - 1 for t in tok[1:4]])
-    return np.array(verts, dtype=np.float64), np.array(faces, dtype=np.int32)
+                if len(tok) < 4:
+                    raise ValueError(f"{path}:{lineno}: face with {len(tok) - 1} corners")
+                corners = []
+                for t in tok[1:]:
+                    try:
+                        i = int(t.split("/")[0])
+                    except ValueError:
+                        raise ValueError(f"{path}:{lineno}: malformed face corner '{t}'") from None
+                    # 1-based; negative = relative to the vertices read so far (-1: the last one)
+                    i = i - 1 if i > 0 else len(verts) + i
+                    if i < 0 or i >= len(verts) or t.split("/")[0] == "0":
+                        raise ValueError(f"{path}:{lineno}: face corner '{t}' refers to a vertex that does not exist (yet)")
+                    corners.append(i)
+                faces.extend(_fan([corners]))
+    return np.array(verts, dtype=np.float64).reshape(-1, 3), np.array(faces, dtype=np.int32).reshape(-1, 3)
 
 
 def write_obj(path, vertices, faces):

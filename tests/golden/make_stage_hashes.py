@@ -1,6 +1,7 @@
 """Writes tests/golden/oracle_stage_hashes.json: SHA-256 of the oracle's Path[] buffers, filter aggregators and RNG
-buffer after ONE seeded sample of two 64x48 scenes (the Cornell box; the Cornell box with a rough-glass icosphere:
-GGX sampling, reflection / transmission, every detmath function).
+buffer after ONE seeded sample of three 64x48 scenes (the Cornell box; the Cornell box with a rough-glass icosphere:
+GGX sampling, reflection / transmission, every detmath function; three spheres that carry the material types the shipped
+table never reaches).
 
 Why: GPU == oracle proves the two agree with EACH OTHER.  Their elementary functions are sibling files
 (oracle/detmath.h, clive2_amd/csrc/detmath.hpp), and an edit applied to both would keep every parity test green while
@@ -25,9 +26,20 @@ def scenes():
     mats = get_materials()
     mats["alpha"][5] = 0.1
     v, f = icosphere(2, radius=2.0, center=(0.0, 1.0, 0.0))
+    # every material type (the shipped table never reaches types 2 and 3, nor type 1 with alpha 0): type 1 smooth,
+    # type 2 (Fresnel-weighted reflect / diffuse, alpha 0.3), type 3 (always reflect, alpha 0.05), one sphere each
+    from clive2_amd import struct_types as st
+    many = np.zeros(10, dtype=st.Material)
+    many[:8] = get_materials()
+    many[8], many[9] = many[5], many[5]
+    many["type"][8], many["alpha"][8] = 2, 0.3
+    many["type"][9], many["alpha"][9] = 3, 0.05
+    many["color"][9, :3] = (0.9, 0.9, 0.9)
+    specs = [dict(mesh=icosphere(2, radius=1.6, center=(x, 0.0, z)), material=m) for x, z, m in ((-3.5, 0.0, 5), (0.0, -1.0, 8), (3.5, 0.0, 9))]
     return {"cornell_64x48": c2.create_scene_from_preset("empty", 64, 48),
             "glass_64x48": c2.create_scene(64, 48, np.array([0, 1.5, 6]), np.array([0, 0, -1]),
-                                           file_specs=[dict(mesh=(v, f), material=5)], materials=mats)}
+                                           file_specs=[dict(mesh=(v, f), material=5)], materials=mats),
+            "all_material_types_64x48": c2.create_scene(64, 48, np.array([0, 1.5, 6]), np.array([0, 0, -1]), file_specs=specs, materials=many)}
 
 
 def oracle_hashes(scene, seed=77):

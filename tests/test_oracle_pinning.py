@@ -289,3 +289,69 @@ def test_detmath_and_light_rays_match_numpy_restatement(oracle_mod):
         oracle_mod.lib().orc_bounce(0, f3([0.1, 0.2, 0.97]), f3([0, 0, 1]), f3([0, 0, 1]), C.c_float(1), C.c_float(1.5),
                                     C.c_float(0), 1, C.c_float(float(rr[k, 0])), C.c_float(float(rr[k, 1])), out)
         assert np.array(out[:3], np.float32).tobytes() == ref[k].tobytes()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Round 4: a SECOND restatement of the two megakernels' loop bookkeeping -- generate_paths
+# (trace.metal:381-532) and connect_paths (:620-869) -- written from the Metal text as scalar Python over the reference's own
+# Ray / Path records (oracle/py_kernels.py), compared with the C oracle bit for bit on 16x16 frames of three scenes: the
+# Cornell box, the rough-glass scene and the scene with every material type.
+def _small_scenes():
+    import clive2_amd as c2
+    from clive2_amd import struct_types as st
+    from clive2_amd.load import get_materials
+    from clive2_amd.meshes import icosphere
+    mats = get_materials()
+    mats["alpha"][5] = 0.1
+    glass = c2.create_scene(16, 16, np.array([0, 1.5, 6]), np.array([0, 0, -1]),
+                            file_specs=[dict(mesh=icosphere(1, radius=2.0, center=(0.0, 1.0, 0.0)), material=5)], materials=mats)
+    many = np.zeros(10, dtype=st.Material)
+    many[:8] = get_materials()
+    many[8], many[9] = many[5], many[5]
+    many["type"][8], many["alpha"][8] = 2, 0.3
+    many["type"][9], many["alpha"][9] = 3, 0.05
+    many["color"][9, :3] = (0.9, 0.9, 0.9)
+    many["alpha"][5] = 0.0                                  # type 1 with alpha 0: the smooth dielectric through the GGX route
+    specs = [dict(mesh=icosphere(1, radius=1.6, center=(x, 0.0, z)), material=m)
+             for x, z, m in ((-3.5, 0.0, 5), (0.0, -1.0, 8), (3.5, 0.0, 9))]
+    all_types = c2.create_scene(16, 16, np.array([0, 1.5, 6]), np.array([0, 0, -1]), file_specs=specs, materials=many)
+    return {"cornell": c2.create_scene_from_preset("empty", 16, 16), "glass": glass, "all_material_types": all_types}
+
+
+@pytest.mark.parametrize("name", ["cornell", "glass", "all_material_types"])
+def test_python_restatement_of_k3_and_k5_equals_the_c_oracle(name, oracle_mod):
+    from oracle import py_kernels as pk
+    scene = _small_scenes()[name]
+    B = 16 * 16
+    o = oracle_mod.OracleRenderer(scene, seeds=oracle_mod.make_seeds(B, seed=4242))
+    for sample in range(2):                                 # the second sample starts from the seeds the first one left
+        o.make_light_rays(); o.make_camera_rays()
+        seeds = o.rand_buffer.copy()
+        o.trace_light_rays()
+        out_l, paths_l = pk.generate_paths(o.light_ray_buffer, o.boxes, o.triangles, o.materials, seeds, oracle_mod.Ray, oracle_mod.Path)
+        assert paths_l.tobytes() == o.out_light_paths.tobytes(), "light Path[] (generate_paths, trace.metal:381-532)"
+        assert out_l.tobytes() == o.out_light_image.tobytes()
+        o.trace_camera_rays()
+        out_c, paths_c = pk.generate_paths(o.camera_ray_buffer, o.boxes, o.triangles, o.materials, seeds, oracle_mod.Ray, oracle_mod.Path)
+        assert paths_c.tobytes() == o.out_camera_paths.tobytes(), "camera Path[]"
+        assert out_c.tobytes() == o.out_camera_image.tobytes(), "unidirectional estimate (trace.metal:523-528)"
+        assert np.array_equal(seeds, o.rand_buffer)
+        o.join_paths()
+        res = pk.connect_paths(o.out_camera_paths, o.out_light_paths, o.triangles, o.materials, o.boxes, o.camera,
+                               oracle_mod.Ray, oracle_mod.WeightAggregator, o.n_light)
+        agg = o.weight_aggregators
+        for f in ("weights", "total_contribution", "contrib_weight_sum"):
+            assert res["aggregators"][f].tobytes() == agg[f].tobytes(), f"aggregator field {f} (connect_paths, trace.metal:620-869)"
+        assert res["out"].tobytes() == o.out_samples.tobytes()
+        assert np.array_equal(res["light_pixel_indices"], o.out_light_indices)
+        assert np.array_equal(res["light_path_indices"], o.out_light_path_indices)
+        assert np.array_equal(res["light_ray_indices"], o.out_light_ray_indices)
+        assert res["light_weights"].tobytes() == o.out_light_weights.tobytes()
+        assert res["light_shade"].tobytes() == o.out_light_shade.tobytes()
+        # the comparison must have had something to compare: long subpaths, t = 1 splats, t >= 2 joins, every material type
+        assert (o.out_camera_paths["length"] >= 4).sum() > 20 and (o.out_light_paths["length"] >= 4).sum() > 20
+        assert (o.out_light_indices >= 0).sum() > 50 and (agg["contrib_weight_sum"] > 0).sum() > 100
+        if name == "all_material_types":
+            seen = set(np.unique(o.out_camera_paths["rays"]["material"][o.out_camera_paths["length"] > 1, 1]).tolist())
+            assert {5, 8, 9} <= seen, seen
+        o.finalize_samples(); o.gather_light_image(); o.process_images()

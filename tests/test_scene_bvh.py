@@ -172,3 +172,88 @@ def test_spatial_split_equals_the_reference_function():
         assert not set(l.tolist()) & set(r.tolist())
         lost += len(ids) - len(l) - len(r)
     assert lost > 0                      # the quirk the fixture documents: straddling triangles belong to neither child
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Round 4: the mesh readers against files in the STANDARD formats that the package's own writers did
+# not produce -- typed by hand (ASCII) or packed with `struct` (binary): tests/golden/meshes/.  What the reference takes from
+# `plyfile` / `objloader` (load.py:76-96) is (vertices, vertex index of every face corner).
+MESHES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "meshes")
+
+
+def test_ply_with_the_stanford_bunny_header():
+    """`x y z confidence intensity` vertices and `list uchar int vertex_indices` faces, ASCII: bun_zipper.ply's header."""
+    from clive2_amd.meshio import read_ply
+    v, f = read_ply(os.path.join(MESHES, "bunny_style_ascii.ply"))
+    assert v.dtype == np.float32 and v.shape == (5, 3) and f.dtype == np.int32
+    np.testing.assert_array_equal(v[0], np.array([-0.0378297, 0.12794, 0.00447467], np.float32))
+    np.testing.assert_array_equal(v[4], np.array([-0.0226054, 0.126675, 0.00715587], np.float32))
+    np.testing.assert_array_equal(f, [[0, 1, 2], [0, 2, 3], [4, 0, 3], [1, 0, 4]])
+
+
+def test_ply_polygons_other_elements_and_property_orders():
+    """double coordinates behind a colour byte, an `edge` element in between, a scalar in front of the corner list, the
+    `vertex_index` spelling, a quad and a pentagon (fan: v0 vi vi+1)."""
+    from clive2_amd.meshio import read_ply
+    v, f = read_ply(os.path.join(MESHES, "quad_and_extras_ascii.ply"))
+    np.testing.assert_array_equal(v, np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0.5, 1.5, 0.25], [-0.5, 0.5, 0.125]], np.float32))
+    np.testing.assert_array_equal(f, [[0, 1, 2], [0, 1, 2], [0, 2, 3], [0, 1, 2], [0, 2, 4], [0, 4, 5]])
+
+
+def test_binary_ply_in_both_byte_orders():
+    from clive2_amd.meshio import read_ply
+    v, f = read_ply(os.path.join(MESHES, "tetra_big_endian.ply"))
+    np.testing.assert_array_equal(v, np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32))
+    np.testing.assert_array_equal(f, [[0, 2, 1], [0, 1, 3], [1, 2, 3], [0, 3, 2]])
+    # little-endian, ushort counts, a quad among triangles (row-by-row path), properties behind the coordinates and the list
+    v, f = read_ply(os.path.join(MESHES, "mixed_little_endian.ply"))
+    np.testing.assert_array_equal(v, np.array([[0, 0, 0], [2, 0, 0], [2, 2, 0], [0, 2, 0], [1, 1, 3]], np.float32))
+    np.testing.assert_array_equal(f, [[0, 1, 2], [0, 2, 3], [0, 1, 4], [1, 2, 4]])
+    with pytest.raises(ValueError, match="truncated"):
+        read_ply(os.path.join(MESHES, "truncated_big_endian.ply"))
+
+
+def test_obj_corner_forms_quads_and_relative_indices():
+    from clive2_amd.meshio import read_obj
+    v, f = read_obj(os.path.join(MESHES, "corners_and_relative.obj"))
+    np.testing.assert_array_equal(v, [[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0.5, 0.5, 1]])
+    np.testing.assert_array_equal(f, [[0, 1, 2], [0, 2, 3], [0, 1, 3], [0, 1, 2], [0, 2, 3], [4, 0, 1], [4, 2, 3]])
+
+
+def test_mesh_readers_refuse_with_a_precise_message(tmp_path):
+    from clive2_amd.meshio import read_obj, read_ply
+    def ply(body, name="x.ply"):
+        p = tmp_path / name
+        p.write_text(body)
+        return str(p)
+    head = "ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nelement face 1\nproperty list uchar int vertex_indices\nend_header\n"
+    with pytest.raises(ValueError, match="refers to vertex"):
+        read_ply(ply(head + "0 0 0\n1 0 0\n0 1 0\n3 0 1 7\n"))
+    with pytest.raises(ValueError, match="2 corners"):
+        read_ply(ply(head + "0 0 0\n1 0 0\n0 1 0\n2 0 1\n"))
+    with pytest.raises(ValueError, match="ends after 2 of 3 rows"):
+        read_ply(ply(head + "0 0 0\n1 0 0\n"))
+    with pytest.raises(ValueError, match="format"):
+        read_ply(ply(head.replace("ascii", "binary_middle_endian")))
+    with pytest.raises(ValueError, match="needs x, y and z"):
+        read_ply(ply(head.replace("property float z\n", "") + "0 0\n1 0\n0 1\n3 0 1 2\n"))
+    with pytest.raises(ValueError, match="unknown PLY scalar type"):
+        read_ply(ply(head.replace("format ascii", "format binary_little_endian").replace("float x", "half x")))
+    obj = tmp_path / "x.obj"
+    obj.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 4\n")
+    with pytest.raises(ValueError, match=r"x\.obj:4: .*does not exist"):
+        read_obj(str(obj))
+    obj.write_text("v 0 0 0\nv 1 0 0\nf 1 2\n")
+    with pytest.raises(ValueError, match="face with 2 corners"):
+        read_obj(str(obj))
+    obj.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 -4\n")
+    with pytest.raises(ValueError, match="does not exist"):
+        read_obj(str(obj))
+
+
+def test_scene_from_a_fixture_mesh_file():
+    """The fixture goes through the same path a user's file takes: fast_load_ply -> create_scene (load.py:88-96)."""
+    import clive2_amd as c2
+    scene = c2.create_scene(32, 24, np.array([0, 1.5, 6]), np.array([0, 0, -1]),
+                            file_specs=[dict(file_path=os.path.join(MESHES, "tetra_big_endian.ply"), material=5, scale=2.0)])
+    assert len(scene.triangles) == 16 + 4 and scene.validate()
