@@ -238,6 +238,7 @@ __device__ __forceinline__ Hit closest_hit(const BvhLds& s, const BvhView& b, V3
 // of node visits, triangle tests and comparisons of each ray is exactly that of closest_hit_impl.
 namespace cl2 {
 
+constexpr int WORK_STRIDE = 16;     // unsigned words per launch slot of the work counters (one 64-byte line)
 constexpr int RAY_CHUNK_MAX = 512;  // rays handed to a wave per global atomic: 64..512, about a quarter of a wave's fair share
 // Lanes whose ray is finished take a new one only when at least REFILL_MIN of them are idle (or nobody is walking).  The
 // refill is all-wave code for a handful of lanes -- a tag load, two dependent vertex gathers, a normalisation and three

@@ -65,7 +65,8 @@ struct cl2_renderer {
     int debug_flags = 0;
     int gather_lanes = 32, gather_wait = 48;   // whole-subpath launch: lanes gathered / steps waited before a wave runs its bounce phase
     int traversal_mode = 0;              // 0 auto, 1 fused (one ray per lane), 2 split (persistent traversal + ray replacement)
-    unsigned* d_work = nullptr;          // [8] work counters of the persistent traversal launches
+    unsigned* d_work = nullptr;          // [8][WORK_STRIDE] work counters of the persistent traversal launches (a 64-byte line per launch slot: the
+                                         // wide walk may split it into eight counters, one per XCD: bvh_wide.hpp)
     int levels_per_launch = 0;           // subpath levels per launch (6 = one launch, 1 = compaction after every bounce, 0 = by survival)
     int levels_auto = 0;                 // the choice made for levels_per_launch == 0 (0 = not made yet)
 
@@ -379,7 +380,7 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
     HIP_TRY(r, hipMemsetAsync(r->d_qcount + 1, 0, 6 * sizeof(unsigned), st));
     const bool split = split_paths(r);
     if (!split) cam0 = 0;
-    if (split) HIP_TRY(r, hipMemsetAsync(r->d_work, 0, 7 * sizeof(unsigned), st));
+    if (split) HIP_TRY(r, hipMemsetAsync(r->d_work, 0, 7 * WORK_STRIDE * sizeof(unsigned), st));
     const int step = split ? 1 : effective_levels(r);
     for (int first = 0; first < MAX_VERTS; first += step) {
         const int end = std::min(first + step, (int)MAX_VERTS);
@@ -400,13 +401,13 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
             // the machine (-20 % VALU): 12.43 -> 12.19 ms per sample on the glass scene, 15.38 -> 15.0 on the blob.
             // debug_flags bit 3 forces it in the serial order too (tests)
             if (wide_walk(r) && (r->pipe_active || ((r->debug_flags >> 3) & 1))) {
-                if (merged) TRY(launch_wide(r, st, 0, c_trav, r->d_work + first, dual, 0));
-                else TRY(launch_wide(r, st, 0, c_trav, r->d_work + first, src, 0));
+                if (merged) TRY(launch_wide(r, st, 0, c_trav, r->d_work + first * WORK_STRIDE, dual, 0));
+                else TRY(launch_wide(r, st, 0, c_trav, r->d_work + first * WORK_STRIDE, src, 0));
                 r->launches_tp++;
             } else {
 #define CL2_PERSIST(CNT, TWO, SRCT, SRC)                                                                                   \
             hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, SRCT>), dim3(persistent_grid_paths(r)), dim3(BLOCK), bvh_lds_bytes(r), \
-                               st, r->bvh, c_trav, r->d_work + first, SRC, r->d_stats, 0)
+                               st, r->bvh, c_trav, r->d_work + first * WORK_STRIDE, SRC, r->d_stats, 0)
 #define CL2_PERSIST_SRC(SRCT, SRC)                                                                                         \
             do {                                                                                                           \
                 if (two_tris_per_step(r)) { if (r->counting) CL2_PERSIST(true, true, SRCT, SRC); else CL2_PERSIST(false, true, SRCT, SRC); } \
@@ -445,7 +446,7 @@ int launch_subpaths(cl2_renderer* r, hipStream_t st, const PathBufs* set, int ki
         if (rc == CL2_OK && (kinds & 2)) rc = launch_trace(r, CL2_CAMERA, st, set, merge ? 2 : 0);
         return rc;
     }
-    HIP_TRY(r, hipMemsetAsync(r->d_work, 0, sizeof(unsigned), st));
+    HIP_TRY(r, hipMemsetAsync(r->d_work, 0, WORK_STRIDE * sizeof(unsigned), st));
     Timed t(r, ST_TRAVERSE_PATHS, st);
     // lanes gathered / steps waited before a wave runs its bounce phase (cl2_set_subpath_gather)
     const int lanes = r->gather_lanes, wait = r->gather_wait;
@@ -498,15 +499,15 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
     {
         Timed t(r, ST_TRAVERSE_CONN, st);
         if (split_conn(r)) {
-            HIP_TRY(r, hipMemsetAsync(r->d_work + 7, 0, sizeof(unsigned), st));
+            HIP_TRY(r, hipMemsetAsync(r->d_work + 7 * WORK_STRIDE, 0, WORK_STRIDE * sizeof(unsigned), st));
             ConnRaySource src{r->d_ctag, lp.P0, cp.P0, r->d_chit[cs],
                               V3{r->cam.focal_point[0], r->cam.focal_point[1], r->cam.focal_point[2]}, B};
             if (wide_walk(r)) {
-                TRY(launch_wide(r, st, 1, r->d_qcount + 7, r->d_work + 7, src, 1));
+                TRY(launch_wide(r, st, 1, r->d_qcount + 7, r->d_work + 7 * WORK_STRIDE, src, 1));
             } else {
 #define CL2_PERSIST(CNT, TWO)                                                                                             \
             hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, ConnRaySource>), dim3(persistent_grid_conn(r)), dim3(BLOCK), bvh_lds_bytes(r), \
-                               st, r->bvh, r->d_qcount + 7, r->d_work + 7, src, r->d_stats, 1)
+                               st, r->bvh, r->d_qcount + 7, r->d_work + 7 * WORK_STRIDE, src, r->d_stats, 1)
             if (two_tris_per_step(r)) { if (r->counting) CL2_PERSIST(true, true); else CL2_PERSIST(false, true); }
             else { if (r->counting) CL2_PERSIST(true, false); else CL2_PERSIST(false, false); }
 #undef CL2_PERSIST
@@ -722,7 +723,7 @@ int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_render
     }
     int rc = CL2_OK;
     if (rc == CL2_OK) rc = dev_alloc(r, &r->d_qcount, (size_t)9);
-    if (rc == CL2_OK) rc = dev_alloc(r, &r->d_work, (size_t)8);
+    if (rc == CL2_OK) rc = dev_alloc(r, &r->d_work, (size_t)8 * WORK_STRIDE);
     if (rc == CL2_OK) rc = dev_alloc(r, &r->d_acc, 8 * (size_t)r->FB);
     if (rc == CL2_OK) rc = dev_alloc(r, &r->d_stats, (size_t)1);
     if (rc != CL2_OK) return bail(rc);
@@ -1877,7 +1878,7 @@ int cl2_probe_traverse(cl2_renderer* r, const void* rays_v, size_t n_rays, int32
     }
     if (rc == CL2_OK && r->traversal_mode == 5 && r->n_wide > 0 && !r->counting) {
         // the probe through the exact 4-wide walk (rays with a non-finite 1/d take the binary walk inside it)
-        if (hipMemsetAsync(r->d_work, 0, sizeof(unsigned), r->stream) != hipSuccess) rc = fail(r, CL2_E_HIP, "probe memset failed");
+        if (hipMemsetAsync(r->d_work, 0, WORK_STRIDE * sizeof(unsigned), r->stream) != hipSuccess) rc = fail(r, CL2_E_HIP, "probe memset failed");
         if (rc == CL2_OK) {
             PathRaySource src{nullptr, d_o, d_d, d_h};
             rc = launch_wide(r, r->stream, 0, d_n, r->d_work, src, 0);
