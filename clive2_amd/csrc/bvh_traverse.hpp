@@ -155,6 +155,25 @@ __device__ __forceinline__ void tri_test(V3 o, V3 d, float4 a0, float4 a1, float
     }
 }
 
+// The same test without early exits and with one predicated update: for waves whose lanes test DIFFERENT triangles (the
+// persistent walks of the mesh scenes) some lane always passes the `u` test, so the exits skip nothing and cost three
+// exec-mask regions of scalar instructions.  Same decisions as tri_test, NaN cases included.
+__device__ __forceinline__ void tri_test_branchless(V3 o, V3 d, const float4& p0, const float4& p1, const float4& p2, int index, Hit& best) {
+    const V3 e1 = v3(p1), e2 = v3(p2);
+    const V3 h = cross(d, e2);
+    const float f = rcp_exact(dot(e1, h));
+    const V3 sv = o - v3(p0);
+    const float u = f * dot(sv, h);
+    const V3 q = cross(sv, e1);
+    const float v = f * dot(d, q);
+    const float t = f * dot(e2, q);
+    const bool ok = !(u < 0 || u > 1) && !(v < 0 || u + v > 1) && (t > DELTA_F && t < best.t);
+    best.tri = ok ? index : best.tri;
+    best.t = ok ? t : best.t;
+    best.u = ok ? u : best.u;
+    best.v = ok ? v : best.v;
+}
+
 // The pruned table of a tiny scene (the Cornell box: three leaves, 16 triangles) has no inner records left: every ray
 // visits record 0, 1, 2, ... in that order, whatever it hits.  The per-lane walk above then spends vector instructions on
 // bookkeeping that is the same in every lane (record index, triangle index, loop tests, LDS addresses) and waits for each

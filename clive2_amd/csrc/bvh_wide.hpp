@@ -285,23 +285,8 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
                 const float4 a0 = ta[0], a1 = ta[1], a2 = ta[2];
                 float4 c0, c1, c2;
                 if (TWO_TRIS) { c0 = tb[0]; c1 = tb[1]; c2 = tb[2]; }
-                auto test = [&](const float4& p0, const float4& p1, const float4& p2, int index) {
-                    const V3 e1 = v3(p1), e2 = v3(p2);
-                    const V3 h = cross(d, e2);
-                    const float f = rcp_exact(dot(e1, h));
-                    const V3 sv = o - v3(p0);
-                    const float u = f * dot(sv, h);
-                    const V3 q = cross(sv, e1);
-                    const float v = f * dot(d, q);
-                    const float t = f * dot(e2, q);
-                    const bool ok = !(u < 0 || u > 1) && !(v < 0 || u + v > 1) && (t > DELTA_F && t < best.t);
-                    best.tri = ok ? index : best.tri;
-                    best.t = ok ? t : best.t;
-                    best.u = ok ? u : best.u;
-                    best.v = ok ? v : best.v;
-                };
-                test(a0, a1, a2, i0);
-                if (TWO_TRIS) test(c0, c1, c2, i1);
+                tri_test_branchless(o, d, a0, a1, a2, i0, best);
+                if (TWO_TRIS) tri_test_branchless(o, d, c0, c1, c2, i1, best);
             }
         }
         // ---- retire: nothing in hand, nothing on the stack ----

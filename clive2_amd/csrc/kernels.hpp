@@ -578,14 +578,13 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
     const int tid = threadIdx.x;
     const int S = wide.stack_lds;
     float4* s_wnodes = cl2_tree_lds;
-    int* s_ref = reinterpret_cast<int*>(cl2_tree_lds + 8 * wide.n_lds_nodes);
-    float* s_tmin = reinterpret_cast<float*>(s_ref) + S * BLOCK;
-    int2* ovf = nullptr;
+    int2* s_stack = reinterpret_cast<int2*>(cl2_tree_lds + 8 * wide.n_lds_nodes) + tid;     // entry e of this lane: s_stack[e * BLOCK] (bvh_wide.hpp)
+    volatile int* ovf = nullptr;                            // volatile: never merged with the LDS access into a flat one
     if (WIDE) {
         for (int i = tid; i < 8 * wide.n_lds_nodes; i += BLOCK) s_wnodes[i] = wide.nodes[i];
         __syncthreads();
         b.n_lds_nodes = 0; b.lds_tris = 0; b.n_fast_nodes = 0;   // the binary records (rays with a non-finite 1/d) come through the caches
-        ovf = wide.overflow + ((size_t)blockIdx.x * BLOCK + tid) * wide.ovf_stride;
+        ovf = reinterpret_cast<volatile int*>(wide.overflow + ((size_t)blockIdx.x * BLOCK + tid) * wide.ovf_stride);
     } else {
         stage_bvh(s, bvh);                                 // ends with the barrier
     }
@@ -637,16 +636,16 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
         n_rays++;
     };
     auto push = [&](int ref, float tmin) {
-        if (sp < S) { s_ref[sp * BLOCK + tid] = ref; s_tmin[sp * BLOCK + tid] = tmin; }
-        else ovf[sp - S] = make_int2(ref, __float_as_int(tmin));
+        if (sp < S) s_stack[sp * BLOCK] = make_int2(ref, __float_as_int(tmin));
+        else { ovf[2 * (sp - S)] = ref; ovf[2 * (sp - S) + 1] = __float_as_int(tmin); }
         sp++;
     };
     auto pop_next = [&]() {
         while (sp > 0 && cur < 0 && tri_i >= tri_end) {
             sp--;
             int ref; float tmin;
-            if (sp < S) { ref = s_ref[sp * BLOCK + tid]; tmin = s_tmin[sp * BLOCK + tid]; }
-            else { const int2 e = ovf[sp - S]; ref = e.x; tmin = __int_as_float(e.y); }
+            if (sp < S) { const int2 e = s_stack[sp * BLOCK]; ref = e.x; tmin = __int_as_float(e.y); }
+            else { ref = ovf[2 * (sp - S)]; tmin = __int_as_float(ovf[2 * (sp - S) + 1]); }
             if (!(tmin < best.t)) continue;
             if (ref >= 0) cur = ref;
             else { const int info = ~ref; tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
@@ -735,26 +734,51 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
             if (WIDE && wlane) {
                 pop_next();
                 if (cur >= 0) {
-                    const float4* nd = cur < wide.n_lds_nodes ? s_wnodes + 8 * cur : wide.nodes + (size_t)8 * cur;
-                    const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
-                    const float4 rf = nd[6];
+                    float4 lx, ly, lz, hx, hy, hz, rf;
+                    if (wide.n_lds_nodes > 0 && cur < wide.n_lds_nodes) {      // the window's lanes read LDS in a branch of their own: no flat loads
+                        const float4* nd = s_wnodes + 8 * cur;
+                        lx = nd[0]; ly = nd[1]; lz = nd[2]; hx = nd[3]; hy = nd[4]; hz = nd[5]; rf = nd[6];
+                        asm volatile("" ::: "memory");
+                    } else {
+                        const float4* __restrict__ nd = wide.nodes + (size_t)8 * cur;
+                        lx = nd[0]; ly = nd[1]; lz = nd[2]; hx = nd[3]; hy = nd[4]; hz = nd[5]; rf = nd[6];
+                    }
                     cur = -1;
                     const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
                     const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
                     const int ref[4] = {__float_as_int(rf.x), __float_as_int(rf.y), __float_as_int(rf.z), __float_as_int(rf.w)};
-                    int next_ref = WIDE_EMPTY;                         // the slot that would pop first skips the stack (bvh_wide.hpp)
-                    float next_tmin = 0.0f;
+                    // round 4, as traverse_wide_persistent: four unconditional slab tests (an empty slot's box lies at +inf), the
+                    // candidate found so far written unconditionally above the top of the stack with `sp += pushed` while every
+                    // visiting lane has room for three entries in the LDS part; the slot that would pop first skips the stack
+                    float tm[4];
+                    bool pass[4];
 #pragma unroll
-                    for (int k = 3; k >= 0; k--) {
-                        if (ref[k] == WIDE_EMPTY) continue;
+                    for (int k = 0; k < 4; k++) {
                         const float t0x = (lox[k] - o.x) * inv.x, t0y = (loy[k] - o.y) * inv.y, t0z = (loz[k] - o.z) * inv.z;
                         const float t1x = (hix[k] - o.x) * inv.x, t1y = (hiy[k] - o.y) * inv.y, t1z = (hiz[k] - o.z) * inv.z;
                         const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
                                                            __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
                         const float tmax = __builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
-                        if (tmin <= tmax && tmin < best.t) {
-                            if (next_ref != WIDE_EMPTY) push(next_ref, next_tmin);
-                            next_ref = ref[k]; next_tmin = tmin;
+                        tm[k] = tmin;
+                        pass[k] = tmin <= tmax && tmin < best.t;
+                    }
+                    int next_ref = pass[3] ? ref[3] : WIDE_EMPTY;
+                    float next_tmin = tm[3];
+                    if (!__any(sp + 3 > S)) {
+#pragma unroll
+                        for (int k = 2; k >= 0; k--) {
+                            s_stack[sp * BLOCK] = make_int2(next_ref, __float_as_int(next_tmin));
+                            sp += (pass[k] && next_ref != WIDE_EMPTY) ? 1 : 0;
+                            next_ref = pass[k] ? ref[k] : next_ref;
+                            next_tmin = pass[k] ? tm[k] : next_tmin;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 2; k >= 0; k--) {
+                            if (pass[k]) {
+                                if (next_ref != WIDE_EMPTY) push(next_ref, next_tmin);
+                                next_ref = ref[k]; next_tmin = tm[k];
+                            }
                         }
                     }
                     if (next_ref == WIDE_EMPTY) pop_next();
@@ -801,8 +825,15 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
                     if (TWO_TRIS) { c0 = b.tris[3 * i1]; c1 = b.tris[3 * i1 + 1]; c2 = b.tris[3 * i1 + 2]; }
                 }
                 if (COUNT) n_tri += two ? 2 : 1;
-                tri_test(o, d, a0, a1, a2, i0, best);
-                if (TWO_TRIS && two) tri_test(o, d, c0, c1, c2, i1, best);
+                if (WIDE) {
+                    // no early exits, one predicated update (bvh_wide.hpp); an odd leaf re-tests its last triangle, which cannot
+                    // pass `t < best_t` a second time
+                    tri_test_branchless(o, d, a0, a1, a2, i0, best);
+                    if (TWO_TRIS) tri_test_branchless(o, d, c0, c1, c2, i1, best);
+                } else {
+                    tri_test(o, d, a0, a1, a2, i0, best);
+                    if (TWO_TRIS && two) tri_test(o, d, c0, c1, c2, i1, best);
+                }
             }
             if (tri_i >= tri_end && ((WIDE && wlane) ? (cur < 0 && sp == 0) : node >= n_nodes)) state = LANE_PEND;
         }

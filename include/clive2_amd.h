@@ -273,8 +273,9 @@ int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
  *   bit 11      walk a pruned table that is a plain list of leaves per lane instead of wave-uniformly (csrc/bvh_traverse.hpp,
  *               closest_hit_flat)
  *   bit 12      invert the one/two-triangles-per-step choice of the persistent walk
- *   bits 16-19  4-wide walk: stack entries per lane in LDS (0 = default 7; at most 8)
- *   bits 20-23  4-wide walk: LDS window in units of 32 wide nodes (0 = default 2)
+ *   bits 16-19  accepted and ignored (round 3: stack entries per lane in LDS of the 4-wide walk; a compile-time 8 since round 4)
+ *   bits 20-23  4-wide walk: LDS window of the top of the wide tree in units of 32 nodes (0 = by tree size: 32 nodes, 64 when
+ *               the tree streams from memory; 15 = no window)
  * Any other bit is refused (CL2_E_INVALID).  Bits 0-2 exist ONLY in the test variant of the library
  * (libclive2_amd_test.so, -DCL2_TEST_VARIANT), where they switch parts of the resolve stage off for timing
  * dissections -- bit 0 the t = 1 splat atomics, bit 1 / bit 2 the t >= 2 / t == 1 strategy pairs -- and make the

@@ -489,6 +489,30 @@ def test_rccl_reduce_path_on_one_rank(tmp_path):
     assert "torch" not in out.split("MODULES")[-1]             # the product path never imported torch
 
 
+def test_bench_line_proves_what_the_communicator_saw(tmp_path):
+    """the job line must show that RCCL saw N ranks on N distinct GPUs -- from the communicator
+    (ncclCommCount / ncclCommUserRank via cl2_comm_info, PCI addresses gathered through the library's all-reduce), not from
+    the launcher's environment -- and what the all-reduce cost.  The N > 1 code path of bench.py on a one-rank communicator
+    (CLIVE2_BENCH_FORCE_COMM=1; RCCL refuses two ranks on one device): `comm` = {nranks 1, one PCI address, allreduce_ms}."""
+    import json, os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CLIVE2_BENCH_FORCE_COMM="1", CLIVE2_RENDEZVOUS_FILE=str(tmp_path / "id"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--width", "320", "--height", "180", "--steps", "6", "--warmup", "1",
+                        "--no-mesh", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1                                     # stdout carries exactly the one JSON line
+    out = json.loads(lines[0])
+    comm = out["comm"]
+    assert comm["nranks"] == 1 and comm["distinct_devices"] == 1 and comm["launcher_world_size"] == 1
+    assert len(comm["devices"]) == 1 and re.fullmatch(r"[0-9a-f]{4}:[0-9a-f]{2}:[0-9a-f]{2}\.[0-7]", comm["devices"][0])
+    assert comm["devices"][0] == comm["rank0_device"].lower()
+    assert comm["allreduce_ms"] >= 0 and comm["allreduce_bytes"] == 8 * 320 * 180 * 4
+    assert out["config"]["sample_streams"] == 1 and "sample-split x1" in out["config"]["parallelism"]
+
+
 def test_written_png_is_upright(tmp_path):
     """The film sits behind the pinhole: row 0 of Renderer.image looks UP at the ceiling light, and the
     reference hands that array to cv2.imwrite unflipped (render.py:47-50).  The PNG written by the CLI

@@ -57,42 +57,67 @@ def main():
         rng = np.random.RandomState(1000 + k)
         scene, desc = random_scene(rng)
         B = scene.pixel_width * scene.pixel_height
-        seeds = make_seeds(B, seed=k)
-        r, o = Renderer(scene, seeds=seeds), orc.OracleRenderer(scene, seeds=seeds)
         mode, levels, stages = int(rng.randint(0, 6)), int(rng.randint(0, 7)), int(rng.randint(-1, 3))
-        r.set_traversal_mode(mode)
-        if rng.rand() < 0.5:                # whole-subpath launch: random register budget and bounce batching, either step form
+        flags = 0
+        gather = None
+        if rng.rand() < 0.5:                # whole-subpath launch: random bounce batching, either step form
             budget, lanes, wait, step = int(rng.choice([0, 4, 5, 6, 7])), int(rng.randint(0, 65)), int(rng.randint(0, 100)), int(rng.randint(0, 2))
-            r.set_debug_flags(step << 12)          # (the register-budget variants of round 2 are gone; the draw stays for the seeds' sake)
-            r.set_subpath_gather(lanes, wait)
+            flags |= step << 12                    # (the register-budget variants of round 2 are gone; the draw stays for the seeds' sake)
+            gather = (lanes, wait)
+        # round 4: K sample streams (stream j = the renderer seeded with buffer j alone) and the wide walk's LDS window (none / 32 / 64 / 96 nodes)
+        K = int(rng.choice([1, 1, 2, 3]))
+        flags |= int(rng.choice([0, 15, 1, 2, 3])) << 20
+        if rng.rand() < 0.3:
+            flags |= 8                             # the 4-wide walk for the per-level subpath launches in the serial order too
+        seeds = [make_seeds(B, seed=k, rank=j) for j in range(K)]
+        r = Renderer(scene, seeds=seeds[0] if K == 1 else np.stack(seeds), streams=K)
+        os_ = [orc.OracleRenderer(scene, seeds=sd) for sd in seeds]
+        o = os_[0]
+        r.set_traversal_mode(mode)
+        r.set_debug_flags(flags)
+        if gather:
+            r.set_subpath_gather(*gather)
         r.set_levels_per_launch(levels)
         r.set_pipelining(stages)
         t0 = time.time()
         ok = True
-        for x in (r, o):
+
+        def same_paths():
+            good = True
+            for j, oj in enumerate(os_):
+                r.set_export_stream(j)
+                good &= r.export_paths(0).tobytes() == oj.out_light_paths.tobytes()
+                good &= r.export_paths(1).tobytes() == oj.out_camera_paths.tobytes()
+            return good
+
+        r.make_light_rays(); r.make_camera_rays(); r.trace_light_rays(); r.trace_camera_rays()
+        for x in os_:
             x.make_light_rays(); x.make_camera_rays(); x.trace_light_rays(); x.trace_camera_rays()
-        ok &= r.export_paths(0).tobytes() == o.out_light_paths.tobytes()
-        ok &= r.export_paths(1).tobytes() == o.out_camera_paths.tobytes()
-        for x in (r, o):
+        ok &= same_paths()
+        r.join_paths(); r.finalize_samples(); r.gather_light_image(); r.process_images()
+        for x in os_:
             x.join_paths(); x.finalize_samples(); x.gather_light_image(); x.process_images()
-        agg = r.export_aggregators()
-        ok &= agg["total_contribution"].tobytes() == o.weight_aggregators["total_contribution"].tobytes()
-        ok &= agg["weights"].tobytes() == o.weight_aggregators["weights"].tobytes()
-        r.run_samples(3); o.run_sample(); o.run_sample(); o.run_sample()
-        ok &= bool(np.array_equal(r.get_random_buffer(), o.rand_buffer))
-        ok &= r.export_paths(0).tobytes() == o.out_light_paths.tobytes()      # the last sample's subpaths
-        ok &= r.export_paths(1).tobytes() == o.out_camera_paths.tobytes()
-        ok &= bool(np.allclose(r.read_accumulators()[3], o.unidirectional_image_buffer, rtol=1e-6, atol=0))
+        for j, oj in enumerate(os_):
+            r.set_export_stream(j)
+            agg = r.export_aggregators()
+            ok &= agg["total_contribution"].tobytes() == oj.weight_aggregators["total_contribution"].tobytes()
+            ok &= agg["weights"].tobytes() == oj.weight_aggregators["weights"].tobytes()
+        r.run_samples(3)
+        for x in os_:
+            x.run_sample(); x.run_sample(); x.run_sample()
+        ok &= bool(np.array_equal(r.get_random_buffer().reshape(K, B, 2), np.stack([x.rand_buffer for x in os_])))
+        ok &= same_paths()                                                    # the last sample's subpaths
+        ok &= bool(np.allclose(r.read_accumulators()[3], sum(x.unidirectional_image_buffer for x in os_), rtol=2e-6 if K > 1 else 1e-6, atol=0))
         img = r.read_accumulators()[0]
-        ok &= bool(np.allclose(img, o.summed_image, rtol=5e-5, atol=1e-8))
-        ok &= r.counters()["rays"] == o.rays_traced
+        ok &= bool(np.allclose(img, sum(x.summed_image for x in os_), rtol=5e-5, atol=1e-8))
+        ok &= r.counters()["rays"] == sum(x.rays_traced for x in os_)
         # the device tone map against the host path on the same accumulators (a byte may move by one where 255*x/(x+w) sits on an integer)
         with np.errstate(all="ignore"):
             for which in ("image", "unidirectional_image"):
                 dv, hv = r.tone_mapped(which), getattr(r, which)
                 dd = np.abs(dv.astype(np.int16) - hv.astype(np.int16))
                 ok &= bool(dd.max() <= 1 and int((dd > 0).sum()) <= 2)
-        print(f"scene {k}: {desc} tris={len(scene.triangles)} mode={mode} levels={levels} stages={stages} "
+        print(f"scene {k}: {desc} tris={len(scene.triangles)} mode={mode} levels={levels} stages={stages} K={K} flags={flags:#x} "
               f"len_c={o.out_camera_paths['length'].mean():.2f} {'OK' if ok else 'MISMATCH'} ({time.time() - t0:.1f}s)", flush=True)
         bad += not ok
         r.close()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX from the repo root: the rocprofv3 passes of one bench.py workload whose summaries go into
 # profiles/ (tools/profile_summaries.py turns gpurun_out/pf_<scene>_* into profiles/<tag>_*_<scene>.*).
-#   bash tools/profile_round.sh [scene=cornell] [steps=32] [pmc_steps=4]
+#   bash tools/profile_round.sh [scene=cornell] [steps=32] [pmc_steps=4] [sample_streams=1]
 # Counters are collected in their own passes, with --kernel-trace only (no other trace domain), FETCH_SIZE and
 # WRITE_SIZE apart (they do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots").
 set -e
@@ -9,8 +9,10 @@ export TMPDIR=/tmp
 SCENE=${1:-cornell}
 STEPS=${2:-32}
 PSTEPS=${3:-4}
+K=${4:-1}
 OUT=gpurun_out
-B="bench.py --scene $SCENE --no-cpu-baseline --no-mesh"
+B="bench.py --scene $SCENE --no-cpu-baseline --no-mesh --sample-streams $K"
+echo $K > $OUT/pf_${SCENE}_streams.txt
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pf_${SCENE}_stats -o runc -- python3 $B --steps $STEPS --warmup 4 > $OUT/pf_${SCENE}_stats.log 2>&1
 echo "stats pass done"

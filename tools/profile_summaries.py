@@ -43,6 +43,7 @@ def main():
     W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1920, 1080)
     import bench
     base = f"gpurun_out/pf_{scene}"
+    streams = int(open(f"{base}_streams.txt").read()) if os.path.exists(f"{base}_streams.txt") else 1
     stats = glob.glob(f"{base}_stats/**/*_kernel_stats.csv", recursive=True)
     if stats:
         shutil.copy(stats[0], f"profiles/{tag}_kernel_stats_{scene}.csv")
@@ -72,10 +73,11 @@ def main():
             [k for k in kernels if k.startswith("k_traverse_persistent<false") and "ConnRaySource" in k] or
             [k for k in kernels if k.startswith("k_traverse_conn<false")])
     out = {"note": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*, TCC_* each in its own run, --kernel-trace only) of "
-                   f"`python3 bench.py --scene {scene} --no-cpu-baseline --no-mesh --steps 4 --warmup 1`; values are averages per launch; "
+                   f"`python3 bench.py --scene {scene} --no-cpu-baseline --no-mesh --sample-streams {streams} --steps 4 --warmup 1`; values are averages per launch "
+                   f"(a launch of a handle with {streams} sample stream(s) carries the rays of {streams} sample(s)); "
                    "FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count, "
                    "MI355X_MICROARCH.md HBM section); SQ_WAVE_CYCLES/SQ_WAIT_*/SQ_ACTIVE_INST_* are quad-cycles",
-           "scene": scene, "width": W, "height": H, "sources_sha": bench.kernel_sources_sha(),
+           "scene": scene, "width": W, "height": H, "sample_streams": streams, "sources_sha": bench.kernel_sources_sha(),
            "conn_traversal_kernel": conn[0] if conn else None, "kernels": kernels}
     json.dump(out, open(f"profiles/{tag}_pmc_{scene}.json", "w"), indent=1, sort_keys=True)
     if stats:
