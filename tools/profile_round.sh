@@ -25,5 +25,5 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 pass tcc TCC_HIT_sum TCC_MISS_sum SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU
-python bench.py --scene $SCENE --no-cpu-baseline --no-mesh --steps $STEPS --warmup 4 > $OUT/pf_${SCENE}_bench.log 2>&1
+python $B --steps $STEPS --warmup 4 > $OUT/pf_${SCENE}_bench.log 2>&1
 tail -1 $OUT/pf_${SCENE}_bench.log | cut -c1-300
