@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _native
 from .distributed import rank_info, samples_for_rank, join_communicator
-from .renderer import Renderer, RendererError, make_seeds
+from .renderer import Renderer, RendererError, stream_seeds
 from .scene import create_scene_from_preset
 
 
@@ -30,6 +30,10 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--device-tonemap", action="store_true",
                     help="tone-map on the device (Renderer.tone_mapped) instead of on the host with numpy (Renderer.image, the reference's path)")
+    ap.add_argument("--sample-streams", type=int, default=1,
+                    help="K independent samples of the frame per pass (Renderer(streams=K): one seed buffer each, as K renderers "
+                         "would hold; pays on mesh scenes, where it makes every launch K times larger); the samples are rounded up "
+                         "to a multiple of K.  1 = the reference's single renderer")
     args = ap.parse_args(argv)
 
     rank, local_rank, world = rank_info()
@@ -39,13 +43,15 @@ def main(argv=None):
         device = local_rank % max(_native.lib().cl2_device_count(), 1)
     else:
         device = args.device
-    renderer = Renderer(scene, seeds=make_seeds(args.width * args.height, rank=rank), device=device)
+    K = max(1, args.sample_streams)
+    # seed buffers of the job: stream k of rank r is buffer r * K + k
+    renderer = Renderer(scene, seeds=stream_seeds(args.width * args.height, K, first_rank=rank * K), device=device, streams=K)
     if world > 1:
         join_communicator(renderer, rank, world)
     t0 = time.time()
     failure = None
     try:
-        renderer.run_samples(samples_for_rank(args.samples, rank, world))
+        renderer.run_samples(-(-samples_for_rank(args.samples, rank, world) // K))
     except (KeyboardInterrupt, RendererError) as e:
         failure = e
     if world > 1:
