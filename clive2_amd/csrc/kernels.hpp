@@ -566,7 +566,7 @@ enum { LANE_IDLE = 0, LANE_TRAV = 1, LANE_PEND = 2 };
 // WIDE: the lanes walk the exact 4-wide collapse of the tree (bvh_wide.hpp: wide node block, per-lane stack in LDS, two
 // triangle pairs per pass) -- except the rays with a non-finite 1/d, which keep the binary walk (records read through
 // the caches), as in traverse_wide_persistent.
-template <bool COUNT, bool TWO_TRIS, int WAVES_PER_SIMD, bool WIDE>
+template <bool COUNT, bool TWO_TRIS, int WAVES_PER_SIMD, bool WIDE, int WIDE_REPS = WIDE_TRI_REPS>
 __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
         BvhView bvh, WideView wide, int B, unsigned* __restrict__ work_counter, PathBufs lp, PathBufs cp, uint2* __restrict__ seeds,
         const float4* __restrict__ tri_shade_g, const MaterialDev* __restrict__ mats_g, int n_mats, Stats* stats,
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
                 }
             }
 #pragma unroll
-            for (int rep = 0; rep < (WIDE ? WIDE_TRI_REPS : 1); rep++)
+            for (int rep = 0; rep < (WIDE ? WIDE_REPS : 1); rep++)       // triangle pairs per pass: 2 while the tree is cache-resident, 1 above (bvh_wide.hpp)
             if (tri_i < tri_end && (rep == 0 || wlane)) {
                 const int i0 = tri_i;
                 const bool two = TWO_TRIS && i0 + 1 < tri_end;

@@ -396,11 +396,12 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
             const PathBufs& cpb = set[CL2_CAMERA];
             DualPathRaySource dual{pb.P0, pb.P1, cpb.P0, cpb.P1, r->d_hit, r->d_hit_cam0, B};
             const unsigned* c_trav = merged ? r->d_qcount + 8 : c_in;
-            // the per-level subpath launches take the 4-wide walk while the sample pipeline runs: alone they are tail-bound and
-            // gain nothing (glass 7.43 -> 7.56 ms), but beside the connection stage what counts is the work they put on
-            // the machine (-20 % VALU): 12.43 -> 12.19 ms per sample on the glass scene, 15.38 -> 15.0 on the blob.
-            // debug_flags bit 3 forces it in the serial order too (tests)
-            if (wide_walk(r) && (r->pipe_active || ((r->debug_flags >> 3) & 1))) {
+            // The per-level subpath launches take the 4-wide walk wherever the scene has it.  Rounds 2 / 3 took it only while the
+            // sample pipeline ran (alone these launches were tail-bound and gained nothing: glass 7.43 -> 7.56 ms); with round 4's
+            // pass the walk is ahead alone as well -- serial order at 3840 x 2160, subpath traversal per sample: blob 15.8 -> 12.6
+            // ms, 1M triangles 44.2 -> 31.8 -- and with sample streams a launch is no longer all tail.  (debug_flags bit 3, which
+            // forced it in the serial order, is accepted and has no effect any more; mode 2 still means the binary walk.)
+            if (wide_walk(r)) {
                 if (merged) TRY(launch_wide(r, st, 0, c_trav, r->d_work + first * WORK_STRIDE, dual, 0));
                 else TRY(launch_wide(r, st, 0, c_trav, r->d_work + first * WORK_STRIDE, src, 0));
                 r->launches_tp++;
@@ -450,8 +451,9 @@ int launch_subpaths(cl2_renderer* r, hipStream_t st, const PathBufs* set, int ki
     Timed t(r, ST_TRAVERSE_PATHS, st);
     // lanes gathered / steps waited before a wave runs its bounce phase (cl2_set_subpath_gather)
     const int lanes = r->gather_lanes, wait = r->gather_wait;
-    // the exact 4-wide walk inside the launch where the scene has it (same rule as the connection rays)
-    const bool widew = wide_walk(r) && two_tris_per_step(r);
+    // the exact 4-wide walk inside the launch where the scene has it (same rule as the connection rays); round 4: also for trees
+    // that stream from memory, with one triangle pair per pass there (as in launch_wide)
+    const bool widew = wide_walk(r);
     WideView w = r->wide;
     w.stack_lds = 8; w.n_lds_nodes = 0;                        // 5 workgroups per CU here (registers): 24 KB each is free
     if (widew) {
@@ -465,11 +467,11 @@ int launch_subpaths(cl2_renderer* r, hipStream_t st, const PathBufs* set, int ki
     // 13.0 -> 13.6 ms on the glass scene, 8 waves 24.5 ms); the grid holds as many workgroups as stay resident
     constexpr int WPS = 5;
     const int grid = std::max(1, persistent_grid_paths(r) * WPS / 8);
-#define CL2_WHOLE(CNT, TWO, WIDE)                                                                                         \
-    hipLaunchKernelGGL((k_subpaths_persistent<CNT, TWO, WPS, WIDE>), dim3(grid), dim3(BLOCK), lds, st, r->bvh, w,          \
+#define CL2_WHOLE(CNT, TWO, WIDE, ...)                                                                                    \
+    hipLaunchKernelGGL((k_subpaths_persistent<CNT, TWO, WPS, WIDE, ##__VA_ARGS__>), dim3(grid), dim3(BLOCK), lds, st, r->bvh, w, \
                        r->B, r->d_work, set[CL2_LIGHT], set[CL2_CAMERA], r->d_seeds, r->d_tri_shade, r->d_mats, r->n_mats, \
                        r->d_stats, lanes, wait, kinds)
-    if (widew) CL2_WHOLE(false, true, true);
+    if (widew) { if (two_tris_per_step(r)) CL2_WHOLE(false, true, true, WIDE_TRI_REPS); else CL2_WHOLE(false, true, true, 1); }
     else if (two_tris_per_step(r)) { if (r->counting) CL2_WHOLE(true, true, false); else CL2_WHOLE(false, true, false); }
     else { if (r->counting) CL2_WHOLE(true, false, false); else CL2_WHOLE(false, false, false); }
 #undef CL2_WHOLE

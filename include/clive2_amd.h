@@ -265,7 +265,8 @@ int cl2_set_profiling(cl2_renderer* r, int level);  /* HIP-event timers: 0 off, 
 int cl2_set_counting(cl2_renderer* r, int on);      /* node / triangle test tallies in the traversal kernels */
 int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
 /* Launch-organisation switches for experiments and tests.  None of them changes a result.
- *   bit 3       the per-level subpath launches take the 4-wide walk in the serial order too
+ *   bit 3       accepted and ignored (rounds 2-3: the per-level subpath launches took the 4-wide walk in the serial order too; they
+ *               always do since round 4)
  *   bits 4-6    7 = the second implementation of the resolve kernel, one wave per camera vertex (only in the test variant
  *               of the library); other values are refused
  *   bit 7       walk the full record table of an LDS-resident tree instead of the pruned one
