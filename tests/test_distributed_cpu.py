@@ -331,3 +331,31 @@ def test_rendezvous_file_is_private_and_fresh(tmp_path):
         assert d.rendezvous_path() != a
     finally:
         os.environ.clear(); os.environ.update(env)
+
+
+def test_two_communicator_bootstraps_over_one_rendezvous_path(tmp_path):
+    """bench.py at N > 1 brings up a second communicator (the strong-scaling leg) through the SAME rendezvous file name after
+    the first one was destroyed: rank 0 removes the file once `comm_init` has returned on it, and no rank reaches the second
+    hand-over before that (the ranks meet rank 0 in collectives in between).  Two hand-overs in a row, three ranks: every rank
+    gets the first id, then the second one -- never the first one twice -- and nothing is left behind."""
+    import threading
+    from clive2_amd import distributed as d
+    path = str(tmp_path / "id")
+    ids = [b"A" * 128, b"B" * 128]
+    got = {r: [] for r in range(3)}
+    barrier = threading.Barrier(3)
+
+    def rank(r):
+        for k in range(2):
+            uid = d.exchange_unique_id(r, 3, lambda: ids[k], 128, path=path, timeout=20.0)
+            got[r].append(uid)
+            barrier.wait()                   # stands for cl2_comm_init_rank (a collective: returns when every rank has the id)
+            d.finish_exchange(r, path)       # rank 0 removes the file
+            barrier.wait()                   # the collectives of the workload between the two bootstraps
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=60)
+    assert all(got[r] == ids for r in range(3)), got
+    assert not os.path.exists(path) and not list(tmp_path.iterdir())
