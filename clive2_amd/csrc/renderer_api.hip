@@ -338,11 +338,7 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
     // LDS per workgroup: per-lane stack (8 B per entry and lane) + the top of the tree (128 B per wide node); experiment
     // switches: debug_flags bits 16-19 stack entries (0 = default), bits 20-23 window in units of 32 wide nodes
     const int sflag = (r->debug_flags >> 16) & 0xF, wflag = (r->debug_flags >> 20) & 0xF;
-    // round 3: 7 stack entries + a 64-node window (22 KB per workgroup, 7 workgroups per CU) instead of 4 + 64 (16 KB, 8).  The
-    // depth of a 4-wide walk is mostly 2..6; with 4 entries in LDS some lane of nearly every wave was past them, and its pushes
-    // and pops went to the global overflow array inside the pass.  ms per sample, same box: glass 9.23 -> 8.81 (7 + 32) / 8.86
-    // (7 + 64), blob 12.17 -> 11.51 / 11.57, 1M triangles 27.28 (7 + 32) / 26.48 (7 + 64) / 26.65 (8 + 64) / 26.53 (7 + 96);
-    // on the small trees 8 + 64 and 6 + 96 lose: 9.25 / 9.28
+    // (round 3 ran 7 stack entries + a 64-node window, 22 KB per workgroup; its measurements are in DESIGN.md 6.1)
     // round 4: WIDE_STACK_LDS (8) entries, a compile-time constant (shift-addressed).  The window's lanes read LDS in a
     // branch of their own (the per-lane pointer select of round 3 made EVERY node fetch a flat load).  Same-box A/B of the
     // rewritten walk, ms (connection launch alone | sample), stack entries + window nodes:

@@ -3,6 +3,9 @@
 ms per SAMPLE per stage, launches and rays of the two traversal stages, and the pipelined figure beside it."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import clive2_amd._native as _n
+if os.environ.get("CL2_LIB"):
+    _n.LIB_PATH = os.path.abspath(os.environ["CL2_LIB"])      # A/B of builds: CL2_LIB=build/lib_x.so
 import bench
 from clive2_amd.renderer import Renderer
 scene, desc = bench.build_scene(sys.argv[1], 1920, 1080)
