@@ -65,8 +65,7 @@ struct cl2_renderer {
     int debug_flags = 0;
     int gather_lanes = 32, gather_wait = 48;   // whole-subpath launch: lanes gathered / steps waited before a wave runs its bounce phase
     int traversal_mode = 0;              // 0 auto, 1 fused (one ray per lane), 2 split (persistent traversal + ray replacement)
-    unsigned* d_work = nullptr;          // [8][WORK_STRIDE] work counters of the persistent traversal launches (a 64-byte line per launch slot: the
-                                         // wide walk may split it into eight counters, one per XCD: bvh_wide.hpp)
+    unsigned* d_work = nullptr;          // [8][WORK_STRIDE] work counters of the persistent traversal launches, a 64-byte line per launch slot
     int levels_per_launch = 0;           // subpath levels per launch (6 = one launch, 1 = compaction after every bounce, 0 = by survival)
     int levels_auto = 0;                 // the choice made for levels_per_launch == 0 (0 = not made yet)
 

@@ -250,3 +250,17 @@ def test_only_device_and_communicator_errors_poison_the_handle():
             r._check(rc, "call")
         assert r._failed
     r._h = None                                  # nothing for __del__ to close
+
+
+@pytest.mark.gpu
+def test_comm_info_without_a_communicator(cornell_small):
+    """cl2_comm_info on a handle that never joined a communicator: nranks 0, and the device fields are filled all the same
+    (the PCI address as an integer and as the runtime's string agree)."""
+    from clive2_amd.renderer import Renderer
+    r = Renderer(cornell_small)
+    info = r.comm_info()
+    assert info["nranks"] == 0 and info["rank"] == 0 and info["device_ordinal"] == 0
+    dom, bus, rest = info["pci_bus_id"].split(":")
+    dev, fn = rest.split(".")
+    assert info["pci_address"] == (int(dom, 16) << 16) | (int(bus, 16) << 8) | (int(dev, 16) << 3) | int(fn, 16)
+    r.close()

@@ -38,3 +38,24 @@ for k in range(400):                       # many short calls: 1, 2, 3, 5 sample
 dt = time.time() - t
 report("cornell 640x360, 400 short calls", r, 1100, dt)
 r.close()
+
+# round 4: sample streams -- 1024 spp of the 82k-triangle scene (BASELINE config 4's sample count) and 256 spp of the 1M-triangle
+# scene with 8 streams, then stream-count changes on a live handle (per-pixel state re-allocated each time, accumulators kept)
+import bench
+for name, spp in (("blob", 1024), ("interior", 256)):
+    s, desc = bench.build_scene(name, 1920, 1080)
+    r = Renderer(s, streams=8)
+    t = time.time(); r.run_samples(spp // 8); dt = time.time() - t
+    report(f"{name} 1920x1080, 8 streams", r, spp, dt)
+    r.close()
+s = c2.create_scene_from_preset("empty", 640, 360)
+r = Renderer(s)
+total, t = 0, time.time()
+for k in range(60):
+    K = (1, 3, 8, 2)[k % 4]
+    r.set_sample_streams(K)
+    r.set_seeds(np.stack([make_seeds(640 * 360, seed=k, rank=j) for j in range(K)]))
+    r.run_samples(3)
+    total += 3 * K
+report("cornell 640x360, 60 stream-count changes", r, total, time.time() - t)
+r.close()
