@@ -30,10 +30,10 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--device-tonemap", action="store_true",
                     help="tone-map on the device (Renderer.tone_mapped) instead of on the host with numpy (Renderer.image, the reference's path)")
-    ap.add_argument("--sample-streams", type=int, default=1,
+    ap.add_argument("--sample-streams", type=lambda v: v if v == "auto" else int(v), default=1,
                     help="K independent samples of the frame per pass (Renderer(streams=K): one seed buffer each, as K renderers "
                          "would hold; pays on mesh scenes, where it makes every launch K times larger); the samples are rounded up "
-                         "to a multiple of K.  1 = the reference's single renderer")
+                         "to a multiple of K.  1 = the reference's single renderer; auto = by scene and frame size (Renderer.auto_streams)")
     args = ap.parse_args(argv)
 
     rank, local_rank, world = rank_info()
@@ -43,9 +43,10 @@ def main(argv=None):
         device = local_rank % max(_native.lib().cl2_device_count(), 1)
     else:
         device = args.device
-    K = max(1, args.sample_streams)
+    renderer = Renderer(scene, device=device, streams=args.sample_streams if args.sample_streams == "auto" else max(1, args.sample_streams))
+    K = renderer.streams
     # seed buffers of the job: stream k of rank r is buffer r * K + k
-    renderer = Renderer(scene, seeds=stream_seeds(args.width * args.height, K, first_rank=rank * K), device=device, streams=K)
+    renderer.set_seeds(stream_seeds(args.width * args.height, K, first_rank=rank * K))
     if world > 1:
         join_communicator(renderer, rank, world)
     t0 = time.time()

@@ -146,3 +146,23 @@ def test_stream_count_changes_and_error_behaviour(cornell_small, oracle_mod):
     r.run_samples(2)
     assert np.array_equal(r.get_random_buffer(), o7.rand_buffer)
     r.close()
+
+
+def test_auto_streams_and_the_render_cli(tmp_path, cornell_small):
+    """`streams="auto"`: 1 for an LDS-resident scene, else what brings a launch to about 2^24 entries (at most 8); the CLI takes
+    `--sample-streams` (a number or auto), rounds the samples up to a multiple of it and writes the picture."""
+    from clive2_amd.renderer import Renderer
+    from clive2_amd import render
+    from PIL import Image
+    r = Renderer(cornell_small, streams="auto")
+    assert r.streams == 1 and r.organisation()["sample_streams"] == 1
+    r.close()
+    r = Renderer(_mesh_scene(80, 45), streams="auto")
+    assert r.streams == 8 and r.get_random_buffer().shape == (8, 80 * 45, 2)
+    r.run_samples(1)
+    assert (r.read_accumulators()[2] == 8).all()
+    r.close()
+    out = tmp_path / "c.png"
+    assert render.main(["--scene", "empty", "--width", "64", "--height", "36", "--samples", "10", "--sample-streams", "4", "--out", str(out)]) == 0
+    assert np.asarray(Image.open(out)).shape == (36, 64, 3)
+    assert render.main(["--scene", "empty", "--width", "64", "--height", "36", "--samples", "3", "--sample-streams", "auto", "--out", str(out)]) == 0
