@@ -264,3 +264,16 @@ def test_comm_info_without_a_communicator(cornell_small):
     dev, fn = rest.split(".")
     assert info["pci_address"] == (int(dom, 16) << 16) | (int(bus, 16) << 8) | (int(dev, 16) << 3) | int(fn, 16)
     r.close()
+
+
+def test_stream_seeds_are_the_seed_buffers_of_consecutive_ranks():
+    """Sample streams use the seed buffers a sample split would: stream k of a handle created with first_rank r gets
+    make_seeds(B, seed, r + k); one stream keeps the reference's (B, 2) shape."""
+    from clive2_amd.renderer import make_seeds, stream_seeds
+    B = 77
+    assert np.array_equal(stream_seeds(B, 1), make_seeds(B))
+    s = stream_seeds(B, 3, first_rank=6)
+    assert s.shape == (3, B, 2) and s.dtype == np.uint32 and (s != 0).all()
+    for k in range(3):
+        assert np.array_equal(s[k], make_seeds(B, rank=6 + k))
+    assert not np.array_equal(s[0], s[1])
