@@ -3,6 +3,10 @@
     generate_paths   src/trace.metal:381-532   (K3: the path loop, importance hand-over, the three colour cases)
     connect_paths    src/trace.metal:620-869   (K5: strategy loop, p-ratio chain, specular zeroing, t == 1 projection, filter weights)
 
+and of the three small kernels behind them -- adaptive_finalize_samples (K6, :981-1018), the light_sort network with its
+driver loop (K7, :872-934 + renderer.py:212-231; not a stable sort, so the order it leaves inside a pixel's run decides float
+sums) and light_image_gather (K8, :937-964) --
+
 written from the Metal text statement by statement -- NOT from oracle/bdpt_oracle.c -- as scalar Python over numpy
 float32 scalars and numpy records in the reference's own Ray / Path / WeightAggregator layouts.  Purpose: the C oracle, the
 HIP kernels and oracle/np_kernels.py were written by one reader of trace.metal; np_kernels.py restates the leaf routines
@@ -672,3 +676,75 @@ def _connect_pixel(id_, camera_path_in, light_path, triangles, materials, c, Ray
     agg["total_contribution"][3] = 0
     agg["contrib_weight_sum"] = contrib_weight_sum
     res["out"][id_] = (total[0], total[1], total[2], 1.0)
+
+
+# ---------------------------------------------------------------- K6, K7 (+ its driver loop), K8
+def adaptive_finalize_samples(aggregators, camera, sample_bin_offsets):
+    """trace.metal:981-1018.  Returns (out float32[B,4], sample_counts uint32[B], sample_weights float32[B])."""
+    c = camera.reshape(-1)[0]
+    W, H = int(c["pixel_width"]), int(c["pixel_height"])
+    B = len(aggregators)
+    out = np.zeros((B, 4), f32)
+    counts = np.zeros(B, np.uint32)
+    sw = np.zeros(B, f32)
+    for id_ in range(B):
+        total = V(0, 0, 0)
+        weight_sum = ZERO
+        for i in range(-1, 2):
+            for j in range(-1, 2):
+                sx, sy = (id_ % W) + i, (id_ // W) + j
+                if sx < 0 or sx >= W or sy < 0 or sy >= H:
+                    continue
+                idx = sy * W + sx
+                if idx < 0 or idx >= W * H:
+                    continue
+                for k in range(int(sample_bin_offsets[idx]), int(sample_bin_offsets[idx + 1])):
+                    wa = aggregators[k]
+                    weight = f32(wa["weights"][1 - i][1 - j])
+                    total = total + weight * v3(wa["total_contribution"])
+                    weight_sum = weight_sum + weight * f32(wa["contrib_weight_sum"])
+        counts[id_] = int(sample_bin_offsets[id_ + 1]) - int(sample_bin_offsets[id_])
+        out[id_] = (total[0], total[1], total[2], 1.0)
+        sw[id_] = weight_sum
+    return out, counts, sw
+
+
+def light_sort_all(pix, path, ray, wgt, shd):
+    """The bitonic network of renderer.py:212-231 driving trace.metal:872-934, all (stage, passOfStage) launches; sorts the five
+    arrays IN PLACE by pixel index.  The pairs of one launch are disjoint, so a launch is one vectorised step."""
+    n = len(pix)
+    log_n = int(np.log2(n))
+    g = np.arange(n // 2, dtype=np.int64)                  # global_pair_id = id * pairs_per_thread + p, id < n / 8, p < 4
+    for stage in range(1, log_n + 1):
+        for pass_of_stage in range(stage, 0, -1):
+            pd, bw = 1 << (pass_of_stage - 1), 1 << stage
+            left = (g // pd) * pd * 2 + (g % pd)
+            right = left + pd
+            ok = (right < n) & (left < n)
+            asc = (g & (bw >> 1)) == 0
+            lp, rp = pix[np.where(ok, left, 0)], pix[np.where(ok, right, 0)]
+            swap = ok & ((asc & (lp > rp)) | (~asc & (lp < rp)))
+            a, b = left[swap], right[swap]
+            for arr in (pix, path, ray, wgt, shd):
+                arr[a], arr[b] = arr[b].copy(), arr[a].copy()
+
+
+def light_image_gather(light_paths, materials, path_indices, ray_indices, bins, offset, weights, shades, sum_weights):
+    """trace.metal:937-964.  Returns light_image float32[B,4]; adds to sum_weights in place."""
+    B = len(light_paths)
+    img = np.zeros((B, 4), f32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        for id_ in range(B):
+            total = V(0, 0, 0)
+            weight_sum = ZERO
+            for i in range(int(bins[id_]) + int(offset), int(bins[id_ + 1]) + int(offset)):
+                path = light_paths[int(path_indices[i])]
+                ray_idx = int(ray_indices[i])
+                ray = path["rays"][ray_idx]
+                prior = path["rays"][max(0, ray_idx - 1)]
+                mat = materials[int(ray["material"])]
+                total = total + ((f32(weights[i]) * f32(shades[i])) * v3(prior["color"])) * v3(mat["color"])
+                weight_sum = weight_sum + f32(weights[i])
+            img[id_] = (total[0], total[1], total[2], 1.0)
+            sum_weights[id_] = f32(sum_weights[id_]) + weight_sum
+    return img

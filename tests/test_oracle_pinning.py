@@ -293,7 +293,7 @@ def test_detmath_and_light_rays_match_numpy_restatement(oracle_mod):
 
 # ---------------------------------------------------------------------------------------------------------
 # Round 4: a SECOND restatement of the two megakernels' loop bookkeeping -- generate_paths
-# (trace.metal:381-532) and connect_paths (:620-869) -- written from the Metal text as scalar Python over the reference's own
+# (trace.metal:381-532) and connect_paths (:620-869) -- and of K6, the sort network and K8, written from the Metal text as scalar Python over the reference's own
 # Ray / Path records (oracle/py_kernels.py), compared with the C oracle bit for bit on 16x16 frames of three scenes: the
 # Cornell box, the rough-glass scene and the scene with every material type.
 def _small_scenes():
@@ -354,4 +354,17 @@ def test_python_restatement_of_k3_and_k5_equals_the_c_oracle(name, oracle_mod):
         if name == "all_material_types":
             seen = set(np.unique(o.out_camera_paths["rays"]["material"][o.out_camera_paths["length"] > 1, 1]).tolist())
             assert {5, 8, 9} <= seen, seen
-        o.finalize_samples(); o.gather_light_image(); o.process_images()
+        # K6, the sort network with its driver loop, K8 (trace.metal:981-1018, :872-934 + renderer.py:212-231, :937-964)
+        sorted_in = [a.copy() for a in (o.out_light_indices, o.out_light_path_indices, o.out_light_ray_indices, o.out_light_weights, o.out_light_shade)]
+        o.finalize_samples()
+        fin, counts, sw = pk.adaptive_finalize_samples(o.weight_aggregators, o.camera, o.summed_bins_buffer)
+        assert fin.tobytes() == o.finalized_samples.tobytes() and np.array_equal(counts, o.sample_counts)
+        assert sw.tobytes() == o.sample_weights.tobytes()
+        o.gather_light_image()
+        pk.light_sort_all(*sorted_in)
+        for mine, theirs in zip(sorted_in, (o.out_light_indices, o.out_light_path_indices, o.out_light_ray_indices, o.out_light_weights, o.out_light_shade)):
+            assert mine.tobytes() == theirs.tobytes(), "bitonic network (not a stable sort: the order inside a pixel's run decides the float sums)"
+        bins, offset = o.light_bins()
+        img = pk.light_image_gather(o.out_light_paths, o.materials, sorted_in[1], sorted_in[2], bins.astype(np.int32), offset, sorted_in[3], sorted_in[4], sw)
+        assert img.tobytes() == o.out_light_image.tobytes() and sw.tobytes() == o.sample_weights.tobytes()
+        o.process_images()
