@@ -857,3 +857,37 @@ def test_c_abi_error_behaviour(cornell_small):
     r.upload_scene(cornell_small)
     r.run_samples(2)
     assert np.isfinite(r.packed_accumulators()).all() and r.counters()["rays"] > 0
+
+
+def test_hip_path_equals_the_python_restatement_directly(oracle_mod):
+    """The HIP kernels against oracle/py_kernels.py -- the second restatement of generate_paths / connect_paths, written from the
+    Metal text separately from the C oracle -- with no C oracle in between except for the first vertices (K1 / K2, which
+    oracle/np_kernels.py restates): both Path[] buffers, the seeds and the filter aggregators of a 16x16 rough-glass frame."""
+    import clive2_amd as c2
+    from clive2_amd.load import get_materials
+    from clive2_amd.meshes import icosphere
+    from clive2_amd.renderer import Renderer, make_seeds
+    from oracle import py_kernels as pk
+    mats = get_materials()
+    mats["alpha"][5] = 0.1
+    scene = c2.create_scene(16, 16, np.array([0, 1.5, 6]), np.array([0, 0, -1]), materials=mats,
+                            file_specs=[dict(mesh=icosphere(1, radius=2.0, center=(0.0, 1.0, 0.0)), material=5)])
+    seeds = make_seeds(256, seed=99)
+    r = Renderer(scene, seeds=seeds)
+    r.make_light_rays(); r.make_camera_rays()
+    first_l, first_c = r.export_rays(LIGHT), r.export_rays(CAMERA)          # the generators' output in the reference's Ray layout
+    sd = r.get_random_buffer().copy()
+    r.trace_light_rays(); r.trace_camera_rays(); r.join_paths()
+    o = oracle_mod                                                         # dtypes only
+    tri, mat, box = (np.ascontiguousarray(a) for a in (scene.triangles, scene.materials, scene.boxes))
+    _, paths_l = pk.generate_paths(first_l.view(o.Ray), box, tri, mat, sd, o.Ray, o.Path)
+    _, paths_c = pk.generate_paths(first_c.view(o.Ray), box, tri, mat, sd, o.Ray, o.Path)
+    assert r.export_paths(LIGHT).tobytes() == paths_l.tobytes()
+    assert r.export_paths(CAMERA).tobytes() == paths_c.tobytes()
+    assert np.array_equal(r.get_random_buffer(), sd)
+    res = pk.connect_paths(paths_c, paths_l, tri, mat, box, np.ascontiguousarray(scene.camera), o.Ray, o.WeightAggregator, 4096)
+    agg = r.export_aggregators()
+    for f in ("weights", "total_contribution", "contrib_weight_sum"):
+        assert agg[f].tobytes() == res["aggregators"][f].tobytes(), f
+    assert (paths_c["length"] >= 4).sum() > 20 and (res["light_pixel_indices"] >= 0).sum() > 30
+    r.close()
