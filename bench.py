@@ -28,12 +28,15 @@ wave64, MI355X_MICROARCH.md) -- the algorithmic-bytes formula of SURVEY.md §8(d
 B_ray = 48 + 32*N_node + 36*N_tri, is reported beside it but prices bytes that never leave LDS.
 Instruction counts and HBM bytes per launch come from committed rocprofv3 PMC passes and are
 marked "static" (used only while the kernel sources still hash to what was profiled).
-`roofline_mesh` is the same launch on the config-3 mesh scene (tree in L2, not LDS), where the
-formula is a memory statement: its bytes are priced against the L2's aggregate bandwidth when the
-tree fits the 32 MiB of L2 (bound "l2"); `roofline_hbm` is the config-5 stand-in (1M triangles, 155 MB
-tree: bound "hbm", 8 TB/s).  The stage-share tuner of the mesh scenes (cl2_tune) runs in the warm-up,
-never inside the clock.  `cpu_baseline` times the C oracle (CPU restatement of the
-reference's kernels, OpenMP over host cores) on a bounded sample.
+The mesh legs -- `roofline_mesh` (config 3), `roofline_blob` (config 4), `roofline_hbm` (config 5 at 1080p) and
+`roofline_hbm_4k` (config 5 at its own 3840 x 2160) -- read their tree through the caches, and say WHICH resource binds the
+launch: every one of them carries `fractions` = {valu_issue, l2, beyond_l2, fabric} (mesh_roofline below), `bound` names the
+largest and `frac` is that one (<= 1).  SURVEY 8(d)'s formula figure (the reference's binary walk, 32 B per node test + 36 B
+per triangle test) is kept beside them as `contract_algorithmic_gbs` with `served_from`: it prices bytes the 4-wide walk does
+not read, against a level they are not served from, and is not a fraction of anything.  The stage-share tuner of the mesh
+scenes (cl2_tune) runs in the warm-up, never inside the clock.  `serial_run_sample_ms` times the reference's own loop --
+`run_sample()` then a read of the tone-mapped picture, every iteration (src/render.py:31-37).  `cpu_baseline` times the C
+oracle (CPU restatement of the reference's kernels, OpenMP over host cores) on a bounded sample.
 """
 import argparse
 import glob
@@ -50,6 +53,10 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL across proc
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 L2_PEAK_GBS = 34500.0      # aggregate L2 bandwidth (8 XCDs x 4 MiB), same guide, "L2 (per XCD)"
 L2_BYTES = 32 << 20
+IC_GATHER_PEAK_GBS = 8600.0   # scattered lines out of the Infinity Cache (38 MB table, uniformly random rows), same guide, "Indexed rows"
+IC_BYTES = 256 << 20
+HBM_ACHIEVABLE_GBS = 6300.0   # what a streaming read gets of the 8 TB/s, same guide, "HBM"
+LINE_BYTES = 128              # one L2 request = one line (tools/l1_gather_rate.hip: a scattered 16-byte load that misses L1 costs a whole line of L2 bandwidth)
 # VALU issue peak: 256 CUs x 4 SIMD-32, a wave64 instruction occupies its SIMD for 2 cycles at 2.4 GHz
 VALU_PEAK_GINST = 1024 * 2.4e9 / 2.0 / 1e9
 
@@ -104,17 +111,69 @@ def static_pmc(scene, W, H, streams=1):
     None when there is no summary for this scene / frame size, or the kernel sources have changed since
     it was taken."""
     sha = kernel_sources_sha()
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{scene}.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{scene}*.json")), reverse=True):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if d.get("sources_sha") != sha or (d.get("width"), d.get("height")) != (W, H) or d.get("sample_streams", 1) != streams:
+        if d.get("scene") != scene or d.get("sources_sha") != sha or (d.get("width"), d.get("height")) != (W, H) or d.get("sample_streams", 1) != streams:
             continue
         row = d.get("kernels", {}).get(d.get("conn_traversal_kernel"))
         if row:
-            return dict(row, source=os.path.relpath(path, ROOT), sources_sha=d["sources_sha"])
+            sub = [k for k in d["kernels"] if k.startswith("k_traverse_wide<") and ",PathRaySource" in k]
+            return dict(row, source=os.path.relpath(path, ROOT), sources_sha=d["sources_sha"],
+                        subpath_kernel=dict(d["kernels"][sub[0]], name=sub[0]) if sub else None)
     return None
+
+
+def mesh_roofline(row, launch_ms, own_bytes, tree_bytes):
+    """What binds a traversal launch whose tree is read through the caches: four fractions, each
+    `achieved / peak` of one resource, from the committed PMC summary `row` of that kernel (per launch, hash-guarded) and the
+    launch time measured live; `bound` = the largest, `frac` = that one.
+      valu_issue   SQ_INSTS_VALU wave-instructions / t against 1024 SIMDs x 2.4 GHz / 2 cycles (active lanes beside it)
+      l2           what L1 asks of L2: (TCC_HIT + TCC_MISS) requests x 128 B / t against the L2's 34.5 TB/s
+      beyond_l2    L2 misses x 128 B / t against the level below: scattered lines out of the Infinity Cache (8.6 TB/s) while
+                   the tree fits its 256 MiB, else HBM (6.3 TB/s achievable of 8)
+      fabric       FETCH_SIZE + WRITE_SIZE as reported (raw) and with the guide's x2 on FETCH_SIZE (calibrated on coalesced
+                   16 B / lane streams; these are scattered 112-byte node and 48-byte triangle reads: both shown) against the
+                   8 TB/s HBM peak; the fraction that decides is the x2 one (the larger)
+    `own_bytes`: what the walk ITSELF asks of L1 per launch (device tallies: 112 B per wide node + 48 B per triangle record +
+    48 B per ray), reported with the share of it that L1 passes on."""
+    if not row or launch_ms <= 0:
+        return None
+    t = launch_ms * 1e-3
+    fr = {}
+    n_valu = row.get("SQ_INSTS_VALU")
+    if n_valu:
+        fr["valu_issue"] = {"achieved": round(n_valu / t / 1e9, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s",
+                            "frac": round(n_valu / t / 1e9 / VALU_PEAK_GINST, 4), "active_lanes_per_inst": row.get("thread_cycles_per_valu_inst"),
+                            "wave_insts_per_launch": n_valu, "wait_share_of_wave_cycles": row.get("wait_share")}
+    hit, miss = row.get("TCC_HIT_sum"), row.get("TCC_MISS_sum")
+    if hit is not None and miss is not None:
+        l2_bytes, below_bytes = (hit + miss) * LINE_BYTES, miss * LINE_BYTES
+        fr["l2"] = {"achieved": round(l2_bytes / t / 1e9, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(l2_bytes / t / 1e9 / L2_PEAK_GBS, 4),
+                    "requests_per_launch": hit + miss, "hit_rate": row.get("l2_hit_rate")}
+        in_ic = tree_bytes <= IC_BYTES
+        peak = IC_GATHER_PEAK_GBS if in_ic else HBM_ACHIEVABLE_GBS
+        fr["beyond_l2"] = {"achieved": round(below_bytes / t / 1e9, 1), "peak": peak, "unit": "GB/s", "frac": round(below_bytes / t / 1e9 / peak, 4),
+                           "served_from": "Infinity Cache (scattered-line rate)" if in_ic else "HBM (achievable streaming rate)", "misses_per_launch": miss}
+    fetch, write = row.get("FETCH_SIZE"), row.get("WRITE_SIZE")
+    if fetch is not None and write is not None:
+        raw, x2 = (fetch + write) * 1024.0, (2 * fetch + write) * 1024.0
+        fr["fabric"] = {"achieved": round(x2 / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(x2 / t / 1e9 / HBM_PEAK_GBS, 4),
+                        "raw_gbs": round(raw / t / 1e9, 1), "raw_frac": round(raw / t / 1e9 / HBM_PEAK_GBS, 4), "x2_gbs": round(x2 / t / 1e9, 1),
+                        "bytes_per_launch_raw": round(raw), "bytes_per_launch_x2": round(x2)}
+    if not fr:
+        return None
+    bound = max(fr, key=lambda k: fr[k]["frac"])
+    out = {"bound": {"valu_issue": "valu", "l2": "l2", "beyond_l2": "infinity_cache" if tree_bytes <= IC_BYTES else "hbm", "fabric": "hbm"}[bound],
+           "bound_fraction": bound, "achieved": fr[bound]["achieved"], "peak": fr[bound]["peak"], "unit": fr[bound]["unit"],
+           "frac": fr[bound]["frac"], "fractions": fr}
+    if own_bytes:
+        out["own_bytes"] = dict(own_bytes, gbs=round(own_bytes["bytes_per_launch"] / t / 1e9, 1))
+        if "l2" in fr:
+            out["own_bytes"]["passed_on_by_l1"] = round(fr["l2"]["requests_per_launch"] * LINE_BYTES / max(own_bytes["bytes_per_launch"], 1), 3)
+    return out
 
 
 _SCENES = {}
@@ -203,11 +262,19 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
     # untimed: the measured launch-organisation choices (bounces per launch of a small scene, stage shares of a large one:
     # cl2_tune, 1 / 42 real samples), then the counting pass that measures N_node / N_tri per ray
     tuned = r.tune()
+    n_count = max(1, -(-max(warmup, 1) // streams))
     r.set_counting(True)
-    r.run_samples(max(1, -(-max(warmup, 1) // streams)))
+    r.run_samples(n_count)
     cw = r.counters()
     n_node = cw["box_tests"] / max(cw["counted_rays"], 1)
     n_tri = cw["tri_tests"] / max(cw["counted_rays"], 1)
+    # what the walk that RUNS fetches (the exact 4-wide walk of the scenes whose tree is read through the caches; counting mode 2)
+    own = None
+    if not r.organisation()["tree_in_lds"] and r.organisation()["wide_nodes"] > 0:
+        r.reset_counters()
+        r.set_counting(2)
+        r.run_samples(n_count)
+        own = r.walk_tallies()
     r.set_counting(False)
     if with_comm:
         r.reduce_accumulators()      # untimed: first use of the collective (channel set-up) before the clock starts
@@ -280,7 +347,7 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
                "peak_gbs": HBM_PEAK_GBS}
         common = {"kernel": k_name, "rays_per_launch": round(rays_per_launch), "avg_launch_ms": round(avg_ms, 4),
                   "avg_launch_ms_alone": round(alone_ms, 4), "traffic": traffic, "active_lanes_per_valu_inst": lanes,
-                  "static": {"what": "traffic, wave_insts_per_launch, active lanes (rocprofv3 PMC passes of this command, committed)",
+                  "static": {"what": "PMC counters per launch (rocprofv3 --pmc passes of this command, committed; quoted only while the kernel sources hash to what was profiled)",
                              "source": pmc["source"], "sources_sha": pmc["sources_sha"]} if pmc else None}
         if in_lds:
             # tree and triangles staged in LDS: the launch is bound by VALU issue, not by HBM
@@ -294,23 +361,50 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
                     "lane_weighted_frac": round(frac * lanes / 64.0, 4) if frac and lanes else None,
                     "wave_insts_per_launch": n_valu, "cycles_per_wave_inst": 2.0, "hbm": hbm}
         else:
-            # the tree is read through the caches: the algorithmic bytes are a memory statement.  Against which level: a tree
-            # that fits the 32 MiB of L2 is served from there (the formula's bytes then exceed what HBM could deliver and are
-            # priced against the L2's bandwidth); a larger one streams from the Infinity Cache / HBM
-            in_l2 = org["tree_bytes"] <= L2_BYTES
-            peak = L2_PEAK_GBS if in_l2 else HBM_PEAK_GBS
-            roof = {"bound": "l2" if in_l2 else "hbm", "achieved": round(alg_gbs, 1), "peak": peak, "unit": "GB/s",
-                    "frac": round(alg_gbs / peak, 4), "frac_launch_alone": round(alg_gbs_alone / peak, 4),
-                    "tree_bytes": org["tree_bytes"], "hbm": hbm}
-            if not in_l2:
-                # `achieved` prices the ALGORITHMIC bytes of SURVEY 8(d) (every node and triangle test of the reference's walk)
-                # against the HBM peak, as the contract defines it.  A tree below 256 MiB lives in the Infinity Cache and its top
-                # levels in L2 / LDS, so those bytes need not come from HBM and the fraction can exceed 1 without any work being
-                # skipped (the device's ray / node-test / triangle-test tallies equal the oracle's at this frame size:
-                # tests/test_gpu_fullsize.py); `traffic` (PMC, HBM-side requests incl. Infinity-Cache hits) and
-                # hbm.measured_frac_of_peak say what actually crosses the fabric.
-                roof["served_from"] = ("Infinity Cache (256 MiB) + L2: the tree is %.0f MB" % (org["tree_bytes"] / 1e6)) if org["tree_bytes"] <= (256 << 20) else "HBM"
-                roof["algorithmic_over_measured_traffic"] = round(rays_per_launch * b_ray / traffic, 3) if traffic else None
+            # The tree is read through the caches.  Which resource binds the launch is decided by four fractions (mesh_roofline):
+            # vector issue, L2 request bandwidth, the level below L2, the fabric.  `own` = what the 4-wide walk itself asks for.
+            def own_bytes(tally, rays_launch):
+                if not tally or not tally["rays"]:
+                    return None
+                per_ray = (112.0 * tally["wide_visits"] + 48.0 * tally["tri_records"] + 32.0 * tally["binary_records"]
+                           + 16.0 * tally["stack_spills"]) / tally["rays"] + 48.0
+                return {"bytes_per_ray": round(per_ray, 1), "bytes_per_launch": round(per_ray * rays_launch),
+                        "wide_visits_per_ray": round(tally["wide_visits"] / tally["rays"], 3),
+                        "tri_records_per_ray": round(tally["tri_records"] / tally["rays"], 3),
+                        "stack_spills_per_ray": round(tally["stack_spills"] / tally["rays"], 4),
+                        "binary_records_per_ray": round(tally["binary_records"] / tally["rays"], 4),
+                        "formula": "112 B x wide-node visits + 48 B x triangle records + 32 B x binary records + 16 B x stack spills (write + read) + 48 B per ray (device tallies, cl2_set_counting(2))"}
+            tree = org["tree_bytes"]
+            roof = mesh_roofline(pmc, avg_ms, own_bytes(own and own["connection"], rays_per_launch), tree)
+            alone = mesh_roofline(pmc, alone_ms, None, tree)
+            if roof is None:
+                # no PMC summary of these sources yet: nothing can be said about the bound (the contract figure below does not say it either)
+                roof = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "fractions": None,
+                        "own_bytes": own_bytes(own and own["connection"], rays_per_launch)}
+            else:
+                roof["frac_launch_alone"] = alone["frac"] if alone else None
+                roof["fractions_launch_alone"] = {k: v["frac"] for k, v in alone["fractions"].items()} if alone else None
+            # SURVEY 8(d)'s formula, as the contract defines it: every node and triangle test of the REFERENCE's binary walk at
+            # 32 / 36 bytes.  A figure, not a fraction: the walk that runs is the 4-wide one, and a tree below 256 MiB is served
+            # by L2 and the Infinity Cache, so these bytes may exceed what HBM could deliver without any work being skipped (the
+            # device's ray / node-test / triangle-test tallies equal the oracle's: tests/test_gpu_fullsize.py)
+            roof["contract_algorithmic_gbs"] = round(alg_gbs, 1)
+            roof["contract"] = {"bytes_per_ray": round(b_ray, 1), "n_node": round(n_node, 3), "n_tri": round(n_tri, 3),
+                                "algorithmic_gbs_launch_alone": round(alg_gbs_alone, 1),
+                                "served_from": ("L2 (32 MiB): the tree is %.1f MB" % (tree / 1e6)) if tree <= L2_BYTES else
+                                               ("Infinity Cache (256 MiB) + L2: the tree is %.0f MB" % (tree / 1e6)) if tree <= IC_BYTES else "HBM",
+                                "algorithmic_over_fabric_traffic": round(rays_per_launch * b_ray / traffic, 3) if traffic else None}
+            roof["tree_bytes"] = tree
+            # the per-level subpath traversal launches (k_traverse_wide<., PathRaySource>): the other big block of a mesh sample
+            sp_launches = max(c["launches_traverse_paths"], 1)
+            sp_ms, sp_rays = c["ms_traverse_paths"] / sp_launches, c["rays_traverse_paths"] / sp_launches
+            sp_row = pmc.get("subpath_kernel") if pmc else None
+            sp = mesh_roofline(sp_row, sp_ms, own_bytes(own and own["subpath"], sp_rays), tree) or {"bound": None, "frac": None}
+            sp.update({"kernel": sp_row["name"] if sp_row else "k_traverse_wide<., PathRaySource>", "launches_per_pass": round(sp_launches / max(passes, 1), 2),
+                       "avg_launch_ms": round(sp_ms, 4), "rays_per_launch": round(sp_rays),
+                       "note": "avg_launch_ms is over ALL subpath traversal launches of the timed region (the merged level-0 launch included); "
+                               "the PMC row is the single-kind launch's"})
+            roof["subpath_walk"] = sp
         roof.update(common)
         roof["sample_streams"] = streams
         out = {"scene_desc": scene_desc, "rays_total": rays_total, "rays_local": rays_local, "dt": dt, "roofline": roof,
@@ -319,6 +413,37 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
                "stages": {k[3:]: round(cb[k] / n_break, 4) for k in cb if k.startswith("ms_")}}
     r.close()
     return out
+
+
+def serial_loop(scene_name, W, H, local_rank, n=8):
+    """The reference's own way of driving a render (src/render.py:31-37): ONE `run_sample()` per iteration, then the picture
+    is read (`Renderer.image` there; here its device-side form `tone_mapped()`, 3 bytes per pixel over PCIe) before the next
+    sample starts -- no sample pipeline, no sample streams, the launch organisation of single calls (whole subpaths in one
+    persistent launch on the mesh scenes).  ms per iteration over `n` iterations after 2 warm-up iterations."""
+    from clive2_amd import _native
+    from clive2_amd.renderer import Renderer, make_seeds
+    scene, _ = build_scene(scene_name, W, H)
+    r = Renderer(scene, seeds=make_seeds(W * H), device=local_rank % max(_native.lib().cl2_device_count(), 1))
+    for _ in range(2):
+        r.run_sample()
+        r.tone_mapped()
+    r.synchronize()
+    t_run = t_map = 0.0
+    for _ in range(n):
+        t0 = time.perf_counter()
+        r.run_sample()
+        t1 = time.perf_counter()
+        pic = r.tone_mapped()
+        t2 = time.perf_counter()
+        t_run += t1 - t0
+        t_map += t2 - t1
+    assert pic.shape == (H, W, 3)
+    rays = r.counters()["rays"] / (n + 2)
+    r.close()
+    return {"ms_per_iteration": round((t_run + t_map) / n * 1e3, 3), "run_sample_ms": round(t_run / n * 1e3, 3),
+            "tone_mapped_read_ms": round(t_map / n * 1e3, 3), "iterations": n,
+            "mrays_per_s": round(rays / ((t_run + t_map) / n) / 1e6, 1),
+            "what": "n x { run_sample(); tone_mapped() } on one handle with one seed buffer: the reference's loop, src/render.py:31-37"}
 
 
 # ---------------------------------------------------------------- N > 1 without an external launcher
@@ -477,7 +602,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-mesh", action="store_true", help="skip the mesh workloads (config 3 and config 5 stand-ins) of the N=1 line")
+    ap.add_argument("--no-mesh", action="store_true", help="skip the mesh workloads (config 3 / 4 / 5 stand-ins) and the serial-loop figures of the N=1 line")
     ap.add_argument("--sample-streams", type=int, default=1,
                     help="sample streams of the headline workload (K independent samples of the frame per pass, cl2_set_sample_streams); "
                          "1 = the reference's single seed buffer per renderer")
@@ -485,6 +610,8 @@ def main():
     ap.add_argument("--strong-spp", type=int, default=1024, help="N > 1: total samples of the strong-scaling leg (config 4 stand-in, split over the ranks); 0 = skip")
     ap.add_argument("--mesh-steps", type=int, default=64)
     ap.add_argument("--hbm-steps", type=int, default=24)
+    ap.add_argument("--hbm4k-steps", type=int, default=8, help="samples of the config-5 leg at its own 3840 x 2160 (0 = skip)")
+    ap.add_argument("--hbm4k-streams", type=int, default=2, help="sample streams of that leg (at 8.3 M pixels a launch is already large)")
     ap.add_argument("--debug-flags", type=int, default=0, help="launch-organisation switches (include/clive2_amd.h); results unchanged")
     ap.add_argument("--scene", default="cornell", choices=["cornell", "glass", "blob", "interior", "open"],
                     help="cornell = the BASELINE metric's workload (default); the others are the mesh configs "
@@ -587,28 +714,40 @@ def main():
             out["comm"] = res["comm"]
         if strong_leg:
             out["strong_scaling"] = strong_leg
+        if world == 1 and not args.no_mesh:
+            out["serial_run_sample_ms"] = serial_loop(args.scene, W, H, local_rank)
         if world == 1 and not args.no_mesh and args.scene == "cornell":
-            # two more workloads on the same line, where the tree is read through the caches and the bytes formula is a
-            # memory statement: config 3 (1,781 boxes / 5,136 triangles: L2-resident -> bound "l2") and config 5 (338 k
-            # boxes / 1 M triangles, 155 MB -> bound "hbm").  Their stage-share tuner runs in the warm-up (cl2_tune).
-            # Each leg runs with --mesh-streams sample streams (every launch then carries K samples' rays: a per-level subpath
+            # The other BASELINE.json configurations a single GPU holds, on the same line -- their tree is read through the caches,
+            # and each leg says which resource binds its dominant launch (mesh_roofline): config 3 (5,136 triangles), config 4
+            # (81,936), config 5 (1,003,536) at 1080p and at its own 3840 x 2160.  Their stage-share tuner runs in the warm-up
+            # (cl2_tune).  Each leg runs with sample streams (every launch then carries K samples' rays: a per-level subpath
             # launch of ONE 1080p sample is 2 M rays on 524 k resident lanes and all tail) and once more with the reference's
-            # single seed buffer (K = 1), reported beside it.
-            for key, name, n_steps in (("roofline_mesh", "glass", args.mesh_steps), ("roofline_hbm", "interior", args.hbm_steps)):
+            # single seed buffer (K = 1), reported beside it, and times the reference's serial loop (serial_run_sample_ms).
+            K = args.mesh_streams
+            legs = (("roofline_mesh", "glass", W, H, args.mesh_steps, K),
+                    ("roofline_blob", "blob", W, H, args.mesh_steps, K),
+                    ("roofline_hbm", "interior", W, H, args.hbm_steps, K),
+                    ("roofline_hbm_4k", "interior", 3840, 2160, args.hbm4k_steps, min(K, args.hbm4k_streams)))
+            for key, name, lw, lh, n_steps, k_leg in legs:
+                if n_steps <= 0:
+                    continue
                 t_setup = time.perf_counter()
-                m = run_workload(args, name, W, H, n_steps, 2, 0, local_rank, 1, with_comm=False, streams=args.mesh_streams)
-                out[key] = dict(m["roofline"], workload=f"{m['scene_desc']} {W}x{H}, {m['steps_rank']} spp in {args.mesh_streams} sample streams",
+                m = run_workload(args, name, lw, lh, n_steps, 2, 0, local_rank, 1, with_comm=False, streams=k_leg)
+                out[key] = dict(m["roofline"], workload=f"{m['scene_desc']} {lw}x{lh}, {m['steps_rank']} spp in {k_leg} sample streams",
                                 mrays_per_s=round(m["rays_total"] / m["dt"] / 1e6, 2),
                                 ms_per_step=round(m["dt"] / m["steps_rank"] * 1e3, 3),
                                 tuner_samples_in_warmup=m["tuner_samples_in_warmup"], paths_share=m["paths_share"],
                                 stage_ms_per_step_serial=m["stages"])
-                if args.mesh_streams != 1:
-                    m1 = run_workload(args, name, W, H, max(8, n_steps // 2), 2, 0, local_rank, 1, with_comm=False, streams=1)
+                if k_leg != 1:
+                    m1 = run_workload(args, name, lw, lh, max(8, n_steps // 2), 2, 0, local_rank, 1, with_comm=False, streams=1)
                     out[key]["one_stream"] = {"sample_streams": 1, "mrays_per_s": round(m1["rays_total"] / m1["dt"] / 1e6, 2),
                                               "ms_per_step": round(m1["dt"] / m1["steps_rank"] * 1e3, 3), "steps": m1["steps_rank"],
-                                              "frac": m1["roofline"]["frac"], "frac_launch_alone": m1["roofline"]["frac_launch_alone"],
+                                              "bound": m1["roofline"]["bound"], "frac": m1["roofline"]["frac"],
+                                              "frac_launch_alone": m1["roofline"].get("frac_launch_alone"),
                                               "avg_launch_ms": m1["roofline"]["avg_launch_ms"], "paths_share": m1["paths_share"]}
+                out[key]["serial_run_sample_ms"] = serial_loop(name, lw, lh, local_rank)
                 out[key]["leg_wall_s"] = round(time.perf_counter() - t_setup, 1)
+                _SCENES.pop((name, lw, lh, None), None)          # a 1M-triangle scene is ~0.5 GB of host arrays: one at a time
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_width, args.cpu_height, args.cpu_samples)
         sys.stdout.flush()

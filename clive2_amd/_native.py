@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_PKG, "libclive2_amd.so")
 # the test variant additionally carries the second implementation of the resolve stage
 # (tests/connect_resolve_wide.hpp, -DCL2_TEST_VARIANT): a cross-check for tests, not shipped code
 TEST_LIB_PATH = os.path.join(_PKG, "libclive2_amd_test.so")
-_MAIN_SOURCES = [os.path.join(_PKG, "csrc", "renderer_api.hip"), os.path.join(_PKG, "csrc", "bvh_builder_gpu.hip")]
+_MAIN_SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("renderer_api.hip", "bvh_builder_gpu.hip", "det_splat.hip")]
 _HEADER = os.path.join(os.path.dirname(_PKG), "include", "clive2_amd.h")
 
 
@@ -62,6 +62,14 @@ class Organisation(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class WalkTally(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "wide_visits", "tri_records", "stack_spills", "binary_records")]
+
+
+class WalkTallies(C.Structure):
+    _fields_ = [("subpath", WalkTally), ("connection", WalkTally)]
+
+
 class CommInfo(C.Structure):
     _fields_ = [("nranks", C.c_int32), ("rank", C.c_int32), ("comm_device", C.c_int32), ("device_ordinal", C.c_int32),
                 ("pci_address", C.c_int64), ("pci_bus_id", C.c_char * 32)]
@@ -79,6 +87,7 @@ EXPORTS = [
     "cl2_export_sample_images", "cl2_probe_traverse", "cl2_probe_math", "cl2_probe_bounce",
     "cl2_tune", "cl2_set_subpath_gather", "cl2_comm_abort", "cl2_tone_log_sum", "cl2_tone_map",
     "cl2_set_sample_streams", "cl2_get_sample_streams", "cl2_set_export_stream", "cl2_comm_info",
+    "cl2_read_walk_tallies", "cl2_set_reproducible", "cl2_get_reproducible",
 ]
 
 

@@ -221,6 +221,14 @@ __device__ __forceinline__ Hit closest_hit_flat(const BvhLds& s, const BvhView& 
     return best;
 }
 
+// Lane index and "set bits of a wave mask below this lane" straight from v_mbcnt: two instructions where they are needed instead
+// of a lane index and a 64-bit lane mask kept alive through a persistent loop (round 4's wide kernels spilled exactly that mask
+// to scratch and reloaded it at the top of every pass).
+__device__ __forceinline__ unsigned wave_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ unsigned rank_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
 __device__ __forceinline__ bool finite3(V3 a) {
     return __builtin_fabsf(a.x) < __builtin_inff() && __builtin_fabsf(a.y) < __builtin_inff() && __builtin_fabsf(a.z) < __builtin_inff();
 }
@@ -274,7 +282,6 @@ constexpr int REFILL_MIN_WIDE = CL2_REFILL_MIN_WIDE;
 template <bool COUNT, bool TWO_TRIS, class Source>
 __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhView& b, unsigned n, unsigned* work_counter,
                                                     const Source& src, unsigned& n_box, unsigned& n_tri) {
-    const int lane = threadIdx.x & 63;
     // chunk size: small launches (one subpath level = one ray per pixel) must still spread over every
     // wave and leave rays for replacement; big launches amortise the atomic
     const unsigned waves = gridDim.x * (blockDim.x >> 6);
@@ -297,14 +304,14 @@ __device__ __forceinline__ void traverse_persistent(const BvhLds& s, const BvhVi
         while (idle && !dry) {
             if (w_next >= w_end) {             // wave-uniform branch: fetch a new chunk
                 unsigned base = 0;
-                if (lane == 0) base = atomicAdd(work_counter, chunk);
+                if (wave_lane() == 0) base = atomicAdd(work_counter, chunk);
                 base = __shfl(base, 0);
                 if (base >= n) { dry = true; break; }
                 w_next = base;
                 w_end = base + chunk < n ? base + chunk : n;
             }
             const unsigned avail = w_end - w_next;
-            const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
+            const unsigned rank = rank_below(idle);
             const bool take = !active && rank < avail;
             if (take) {
                 key = src.load(w_next + rank, o, d);

@@ -79,16 +79,22 @@ struct WideView {
 //     `u` test, so the exits only cost scalar instructions; one predicated update at the end, identical decisions
 //     (NaN included: `!(u < 0 || u > 1)` etc. are kept in that form).  The second triangle of a pair is tested
 //     unconditionally: a leaf with an odd count re-tests its last triangle, which cannot pass `t < best_t` a second time;
-//   * no LDS window of the top of the tree by default: plain global loads served by L1 / L2 (a window can still be asked for:
-//     its lanes read LDS in their own branch, kept apart from the global one).
+//   * the LDS window of the top of the tree (launch_wide: 32 wide nodes while the tree is cache-resident, 64 when it streams
+//     from memory) is read in a branch of its own, kept apart from the global loads of the nodes below it -- never through a
+//     per-lane pointer select.
 // Per ray the sequence of box tests, triangle tests and comparisons is unchanged (same parity tests, same fuzz).
 constexpr int WIDE_NT = 256;                  // threads per workgroup of the wide launches (BLOCK)
 constexpr int WIDE_S = WIDE_STACK_LDS;        // stack entries per lane in LDS
 
 // TRI_REPS: triangle pairs a lane in a leaf tests per pass (WIDE_TRI_REPS = 2 while the tree is cache-resident; 1 when it streams
 // from memory: round 4, same box, 1M triangles: connection launch 11.2 -> 10.7 ms, sample 22.3 -> 21.3 ms).
-template <int TRI_REPS, class Source>
-__device__ __forceinline__ void traverse_wide_persistent(const WideView& w, const BvhView& b, unsigned n, unsigned* work_counter, const Source& src) {
+// TALLY (cl2_set_counting(2)): per-lane counts of what THIS walk fetches -- wide nodes visited, distinct triangle records read,
+// stack entries that went to the global overflow array, binary records of the rays with a non-finite 1/d -- for the bytes the
+// kernel itself asks of the memory system (bench.py: own bytes = 112 B per wide node + 48 B per triangle record + 48 B per ray).
+struct WalkTally { unsigned visits = 0, tri_records = 0, spills = 0, bin_nodes = 0; };
+
+template <int TRI_REPS, bool TALLY, class Source>
+__device__ __forceinline__ void traverse_wide_persistent(const WideView& w, const BvhView& b, unsigned n, unsigned* work_counter, const Source& src, WalkTally& tally) {
     constexpr bool TWO_TRIS = true;
     extern __shared__ float4 cl2_tree_lds[];
     const int tid = threadIdx.x;
@@ -101,7 +107,6 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
         __syncthreads();
     }
     volatile int* ovf = reinterpret_cast<volatile int*>(w.overflow + ((size_t)blockIdx.x * NT + tid) * w.ovf_stride);
-    const int lane = tid & 63;
     const unsigned waves = gridDim.x * (NT >> 6);
     unsigned chunk = n / (waves * 4u);
     chunk = chunk < 64u ? 64u : (chunk > (unsigned)RAY_CHUNK_MAX ? (unsigned)RAY_CHUNK_MAX : chunk);
@@ -144,14 +149,14 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
         while (idle && !dry) {
             if (w_next >= w_end) {
                 unsigned base = 0;
-                if (lane == 0) base = atomicAdd(work_counter, chunk);
+                if (wave_lane() == 0) base = atomicAdd(work_counter, chunk);
                 base = __shfl(base, 0);
                 if (base >= n) { dry = true; break; }
                 w_next = base;
                 w_end = base + chunk < n ? base + chunk : n;
             }
             const unsigned avail = w_end - w_next;
-            const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
+            const unsigned rank = rank_below(idle);
             if (!active && rank < avail) {
                 key = src.load(w_next + rank, o, d);
                 inv = rcp3(d);
@@ -185,6 +190,7 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
             if (active && !wlane && tri_i >= tri_end && node < n_nodes) {
                 const float4 lo = b.nodes[2 * node], hi = b.nodes[2 * node + 1];
                 const int next = __float_as_int(lo.w);
+                if (TALLY) tally.bin_nodes++;
                 const float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
                 const float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
                 const float tmin = max_msl(max_msl(min_msl(t0x, t1x), min_msl(t0y, t1y)), max_msl(min_msl(t0z, t1z), 0.0f));
@@ -216,6 +222,7 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
                     lx = nd[0]; ly = nd[1]; lz = nd[2]; hx = nd[3]; hy = nd[4]; hz = nd[5]; rf = nd[6];
                 }
                 cur = -1;
+                if (TALLY) tally.visits++;
                 const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
                 const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
                 const int ref[4] = {__float_as_int(rf.x), __float_as_int(rf.y), __float_as_int(rf.z), __float_as_int(rf.w)};
@@ -252,7 +259,7 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
                         if (pass[k]) {
                             if (next_ref != WIDE_EMPTY) {
                                 if (sp < WIDE_S) s_stack[sp * NT] = make_int2(next_ref, __float_as_int(next_tmin));
-                                else { ovf[2 * (sp - WIDE_S)] = next_ref; ovf[2 * (sp - WIDE_S) + 1] = __float_as_int(next_tmin); }
+                                else { ovf[2 * (sp - WIDE_S)] = next_ref; ovf[2 * (sp - WIDE_S) + 1] = __float_as_int(next_tmin); if (TALLY) tally.spills++; }
                                 sp++;
                             }
                             next_ref = ref[k]; next_tmin = tm[k];
@@ -280,6 +287,7 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
                 const int i0 = tri_i;
                 const int i1 = (TWO_TRIS && i0 + 1 < tri_end) ? i0 + 1 : i0;
                 tri_i = i1 + 1;
+                if (TALLY) tally.tri_records += (i1 != i0) ? 2u : 1u;
                 const float4* __restrict__ ta = w.tris + (size_t)3 * i0;
                 const float4* __restrict__ tb = w.tris + (size_t)3 * i1;
                 const float4 a0 = ta[0], a1 = ta[1], a2 = ta[2];
@@ -299,7 +307,7 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
             const int a = __popcll(__ballot(h_node)), bb = __popcll(__ballot(h_t0)), c = __popcll(__ballot(h_t1)), dd = __popcll(__ballot(!h_node && !h_t0));
             int spmax = active ? sp : 0;
             for (int off = 32; off > 0; off >>= 1) { const int other = __shfl_xor(spmax, off); spmax = other > spmax ? other : spmax; }
-            if (lane == 0) {
+            if (wave_lane() == 0) {
                 atomicAdd(&g_walk_histo[0][a], 1ull); atomicAdd(&g_walk_histo[1][bb], 1ull);
                 atomicAdd(&g_walk_histo[2][c], 1ull); atomicAdd(&g_walk_histo[3][dd], 1ull);
                 atomicAdd(&g_walk_histo[5][spmax > 64 ? 64 : spmax], 1ull);

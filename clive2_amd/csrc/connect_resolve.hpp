@@ -47,7 +47,10 @@ __device__ __forceinline__ V3 lds_v3(const float* base, int v) {
 }
 
 // One strategy pair with s = S (compile time).  Returns true when a contribution was produced.
-template <int S>
+// DET (cl2_set_reproducible): a t = 1 contribution is not added to the light image with float atomics but WRITTEN as a record
+// {target pixel, source slot} / {c.xyz, w} at slot (S-1) * B + pid -- the reference's own scatter `id + s * total_pixels`
+// (trace.metal:817-823) -- and summed per target pixel in a fixed order afterwards (det_splat.hpp).
+template <int S, bool DET>
 __device__ __forceinline__ void resolve_pair(
         int t, int B, int pid, const LightVtx (&lv)[MAX_VERTS], const float (&GL)[MAX_VERTS], const float (&RL)[MAX_VERTS],
         unsigned l_spec, unsigned c_spec, bool spec7,
@@ -56,7 +59,8 @@ __device__ __forceinline__ void resolve_pair(
         V3 prior_camera_color, const float* GCs, const float* RCs /* [m*BLOCK + tid] */, const float* LNs, const float* LCs,
         unsigned long long mask, float2 h, const float4* __restrict__ tri_shade, const CamTris& cam_tris,
         const MaterialDev* __restrict__ mats, const CameraRec& cam, V3 focal, V3 cam_dir,
-        V3& total, float& contrib_weight_sum, float4* __restrict__ light_image, float* splat_tab, int debug_flags) {
+        V3& total, float& contrib_weight_sum, float4* __restrict__ light_image, float* splat_tab, int debug_flags,
+        unsigned long long* __restrict__ det_keys, float4* __restrict__ det_vals) {
     const int tid = threadIdx.x;
     V3 c_o = c_o_in, c_n = c_n_in;
     float c_tot = c_tot_in, c_cos = c_cos_in;
@@ -171,6 +175,12 @@ __device__ __forceinline__ void resolve_pair(
             // the light image of THIS entry's sample stream (computed here, in the rare branch, not carried through the kernel:
             // it runs at 162 of 168 VGPRs)
             const int splat_idx = (pid - pid % frame_pixels) + light_pixel_idx;
+            if (DET) {
+                const size_t rec = (size_t)(S > 0 ? S - 1 : 0) * B + pid;
+                det_vals[rec] = make_float4(c.x, c.y, c.z, w);
+                det_keys[rec] = ((unsigned long long)(unsigned)splat_idx << 32) | (unsigned long long)rec;
+                return;
+            }
             // Splat {c.xyz, w} into light_image[pixel] (float4).  The lanes that reach this point
             // exchange their 4 values through a per-wave LDS table so that four CONSECUTIVE lanes
             // add the four components of one pixel: each atomic wave-instruction then carries whole
@@ -211,12 +221,13 @@ __device__ __forceinline__ void resolve_pair(
     }
 }
 
-template <int WAVES_PER_SIMD, bool MATS_LDS>
+template <int WAVES_PER_SIMD, bool MATS_LDS, bool DET = false>
 __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
         int B, PathBufs lp, PathBufs cp, const MaterialDev* __restrict__ mats_g, int n_mats,
         const float4* __restrict__ tri_shade, CamTris cam_tris, CameraRec cam, const unsigned long long* __restrict__ cmask,
         const float2* __restrict__ chit, float* __restrict__ agg, float4* __restrict__ light_image,
-        float4* __restrict__ uni_out, Stats* stats, int debug_flags) {
+        float4* __restrict__ uni_out, Stats* stats, int debug_flags,
+        unsigned long long* __restrict__ det_keys, float4* __restrict__ det_vals) {
     __shared__ float GCs[(MAX_VERTS - 1) * BLOCK];     // GC[v] = G(camera[v], camera[v+1])
     __shared__ float RCs[(MAX_VERTS - 1) * BLOCK];     // RC[m]: ratio of camera vertex m with both neighbours on the camera side
     __shared__ float LNs[3 * MAX_VERTS * BLOCK];       // light vertex normals
@@ -349,9 +360,9 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
 #endif
 #define CL2_PAIR(S)                                                                                             \
         if ((S) <= Ll && t + (S) >= 2)                                                                          \
-            resolve_pair<S>(t, B, pid, lv, GL, RL, l_spec, c_spec, spec7, c_o, c_n, cP0.w, cP1.w, cP3.w, c_cos, \
+            resolve_pair<S, DET>(t, B, pid, lv, GL, RL, l_spec, c_spec, spec7, c_o, c_n, cP0.w, cP1.w, cP3.w, c_cos, \
                             c_tri, c_meta, prior_camera_color, GCs, RCs, LNs, LCs, mask, hits[S], tri_shade, cam_tris, mats, cam, \
-                            focal, cam_dir, total, contrib_weight_sum, light_image, splat_tab, debug_flags)
+                            focal, cam_dir, total, contrib_weight_sum, light_image, splat_tab, debug_flags, det_keys, det_vals)
         CL2_PAIR(0); CL2_PAIR(1); CL2_PAIR(2); CL2_PAIR(3); CL2_PAIR(4); CL2_PAIR(5); CL2_PAIR(6);
 #undef CL2_PAIR
     }

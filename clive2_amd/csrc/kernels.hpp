@@ -72,6 +72,10 @@ struct PathBufs {
 
 struct Stats {   // device-side tallies
     unsigned long long rays, box_tests, tri_tests, conn_rays, counted_rays;
+    // cl2_set_counting(2): what the 4-wide walk ITSELF fetched (not the reference's walk, whose tallies the fields above hold):
+    // [0] subpath launches, [1] connection launches; {rays, wide-node visits, triangle records, stack entries spilled to the
+    // global overflow array, binary records visited by rays with a non-finite 1/d}
+    unsigned long long walk[2][5];
 };
 
 __device__ __forceinline__ V3 cam3(const float* p) { return v3(p[0], p[1], p[2]); }
@@ -284,6 +288,28 @@ struct ConnRaySource {          // connection rays: tag {slot, pixel} -> light v
     }
 };
 
+// Round 5: the same rays with their DIRECTION taken from the queue.  k_connect_setup normalises `target - origin` for its culls
+// anyway (trace.metal:684-688); its writing pass stores that direction beside the tag -- one float4 {d.xyz, tag} per ray -- and the
+// refill of the persistent walks reads it instead of gathering the second vertex and normalising again (a dependent gather,
+// a square root and an exact reciprocal per ray, in all-wave code that runs for a handful of lanes).  Same subtraction, same
+// normalize() on the same operands: the ray is bit for bit the one ConnRaySource rebuilds.
+struct ConnDirRaySource {
+    const float4* cdir; const float4* LP0; float2* chit; int B;
+    __device__ __forceinline__ int load(unsigned j, V3& o, V3& d) const {
+        const float4 c = cdir[j];
+        const int tag = __float_as_int(c.w);
+        const int pid = tag & ((1 << TAG_PID_BITS) - 1), slot = (unsigned)tag >> TAG_PID_BITS;
+        const int s = slot % 6 + 1;
+        o = v3(LP0[(size_t)(s - 1) * B + pid]);
+        d = v3(c);
+        return tag;
+    }
+    __device__ __forceinline__ void store(int tag, const Hit& h) const {
+        const int pid = tag & ((1 << TAG_PID_BITS) - 1), slot = (unsigned)tag >> TAG_PID_BITS;
+        chit_store(chit, B, slot, pid, h.tri, h.t);
+    }
+};
+
 // SGPR budget: 256-thread workgroups are admitted per CU up to floor(800 / (ceil(sgprs / 16) * 16 + 16)) -- 8 up to 80
 // SGPRs, 7 from 81 (MI355X_MICROARCH.md, "Residency").  Left alone the compiler takes 81 for the connection-ray
 // instantiation: one workgroup in eight of the persistent grid then never becomes resident beside the others.
@@ -311,14 +337,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(78))) void k_
 }
 
 // The same launch shape over the 4-wide collapse of the tree (bvh_wide.hpp): exact, half the dependent fetches.
-template <int TRI_REPS, class Source>
-__global__ __launch_bounds__(BLOCK, 8) __attribute__((amdgpu_num_sgpr(80))) void k_traverse_wide(WideView wide, BvhView bvh, const unsigned* __restrict__ count,
+// (The ray tally is added BEFORE the walk: `threadIdx.x == 0` after it would keep the thread index alive through the whole loop,
+// in a kernel held to 64 VGPRs -- round 4's builds spilled exactly that register to scratch at entry and reloaded it at exit.)
+// The tallying variant (cl2_set_counting(2), never timed) carries four more counters per lane and takes 6 waves per SIMD.
+template <int TRI_REPS, class Source, bool TALLY = false>
+__global__ __launch_bounds__(BLOCK, TALLY ? 6 : 8) __attribute__((amdgpu_num_sgpr(80))) void k_traverse_wide(WideView wide, BvhView bvh, const unsigned* __restrict__ count,
                                                         unsigned* __restrict__ work_counter, Source src, Stats* stats, int is_conn) {
     const unsigned n = *count;
-    traverse_wide_persistent<TRI_REPS>(wide, bvh, n, work_counter, src);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&stats->rays, (unsigned long long)n);
         if (is_conn) atomicAdd(&stats->conn_rays, (unsigned long long)n);
+        if (TALLY) atomicAdd(&stats->walk[is_conn ? 1 : 0][0], (unsigned long long)n);
+    }
+    WalkTally tally;
+    traverse_wide_persistent<TRI_REPS, TALLY>(wide, bvh, n, work_counter, src, tally);
+    if (TALLY) {
+        unsigned v[4] = {tally.visits, tally.tri_records, tally.spills, tally.bin_nodes};
+        for (int off = 32; off > 0; off >>= 1)
+            for (int k = 0; k < 4; k++) v[k] += __shfl_down(v[k], off);
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
+            for (int k = 0; k < 4; k++) atomicAdd(&stats->walk[is_conn ? 1 : 0][1 + k], (unsigned long long)v[k]);
     }
 }
 
@@ -430,8 +468,10 @@ __device__ __forceinline__ BounceOut shade_and_bounce(bool from_camera, const Hi
     return out;
 }
 
+// (EXT_HIT, the bounce launch of the per-level organisation: five waves per SIMD.  At six -- 80 VGPRs -- it spilled one temporary
+// of the bounce arithmetic; round 4 measured 5 and 6 waves equal: 1.14 ms per sample on the glass scene, 7 and 8 slower.)
 template <bool FROM_CAMERA, bool COUNT, bool EXT_HIT>
-__global__ __launch_bounds__(BLOCK, 6) void k_trace_subpath(
+__global__ __launch_bounds__(BLOCK, EXT_HIT ? 5 : 6) void k_trace_subpath(
         BvhView bvh, Stats* stats, int first, int end, const int* __restrict__ queue_in,
         const unsigned* __restrict__ count_in, int* __restrict__ queue_out, unsigned* __restrict__ count_out, int B,
         PathBufs pb, uint2* __restrict__ seeds, const float4* __restrict__ tri_shade_g,
@@ -591,7 +631,6 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
     // shading records and the (tiny) material table are read through the caches: this launch is for trees
     // that do not fit LDS, whose shading triangles do not either
     const ShadeSrc src{nullptr, false, false, tri_shade_g, mats_g};
-    const int lane = threadIdx.x & 63;
     const unsigned n = (unsigned)B;
     const unsigned waves = gridDim.x * (blockDim.x >> 6);
     unsigned chunk = n / (waves * 4u);
@@ -660,14 +699,14 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
         while (idle && !dry) {
             if (w_next >= w_end) {
                 unsigned base = 0;
-                if (lane == 0) base = atomicAdd(work_counter, chunk);
+                if (wave_lane() == 0) base = atomicAdd(work_counter, chunk);
                 base = __shfl(base, 0);
                 if (base >= n) { dry = true; break; }
                 w_next = base;
                 w_end = base + chunk < n ? base + chunk : n;
             }
             const unsigned avail = w_end - w_next;
-            const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
+            const unsigned rank = rank_below(idle);
             if (state == LANE_IDLE && rank < avail) {
                 pid = (int)(w_next + rank);
                 cam = !(kinds & 1); level = 0; plen = 0; seeds_dirty = false;
@@ -843,7 +882,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
         n_rays += __shfl_down(n_rays, off);
         if (COUNT) { n_box += __shfl_down(n_box, off); n_tri += __shfl_down(n_tri, off); }
     }
-    if (lane == 0) {
+    if (wave_lane() == 0) {
         atomicAdd(&stats->rays, (unsigned long long)n_rays);
         if (COUNT) {
             atomicAdd(&stats->box_tests, (unsigned long long)n_box);
@@ -891,9 +930,16 @@ __device__ __forceinline__ size_t clamped_pid(bool valid, int pid) { return vali
 // {slot, pixel}.  Tags are ordered wave-by-wave, slot-major inside a wave, so consecutive queue
 // entries are the same (t,s) strategy of neighbouring pixels: the vertex gathers of
 // k_traverse_conn are coalesced and its rays coherent.
-__global__ __launch_bounds__(BLOCK, 6) void k_connect_setup(
+// WRITE_DIR (the persistent walks' queue, ConnDirRaySource): the writing pass emits {direction, tag} (16 B per ray) into `cdir`
+// instead of the 4-byte tag into `ctag`; the direction is recomputed there for the pairs that passed (the kernel waits for memory
+// four fifths of its time: the arithmetic is free, the 12 extra bytes per ray are not -- which is why the LDS-resident scenes,
+// whose walk is bound by vector issue and saves ~2 % of it, keep the tags).
+// (The direction-writing form keeps the light origins alive across its barrier; it runs beside persistent launches, held to four
+// workgroups per CU by its LDS pad (launch_connect), so it may as well have the registers of four waves per SIMD.)
+template <bool WRITE_DIR>
+__global__ __launch_bounds__(BLOCK, WRITE_DIR ? 4 : 6) void k_connect_setup(
         int B, PathBufs lp, PathBufs cp, const MaterialDev* __restrict__ mats, int n_mats, CameraRec cam,
-        int* __restrict__ ctag, unsigned* __restrict__ ccount, unsigned long long* __restrict__ cmask) {
+        int* __restrict__ ctag, float4* __restrict__ cdir, unsigned* __restrict__ ccount, unsigned long long* __restrict__ cmask) {
     __shared__ unsigned s_wave_total[WAVES_PER_BLOCK];
     __shared__ unsigned s_base;
     __shared__ int s_mtype[256];                           // material types (the table has at most 256 entries, cl2_upload_scene)
@@ -969,12 +1015,29 @@ __global__ __launch_bounds__(BLOCK, 6) void k_connect_setup(
     // pass 2: write the ray tags {slot, pixel}; k_traverse_conn rebuilds the ray from the two vertices
 #pragma unroll
     for (int t = 1; t <= MAX_VERTS; t++) {
+        V3 target = focal;
+        if (WRITE_DIR && t > 1) {
+            // camera vertex t-1 again (read in pass 1, three vertices ago: served by the caches); fetched when SOME lane has it
+            float4 c0 = make_float4(0, 0, 0, 0);
+            if (__builtin_amdgcn_ballot_w64(t <= Lc) != 0ull) c0 = cp.P0[(t - 1) * vB + lpid];
+            target = v3(c0);
+        }
 #pragma unroll
         for (int s = 1; s <= MAX_VERTS; s++) {
             const int slot = conn_slot(t, s);
             const bool pred = (mine >> slot) & 1ull;
             const unsigned long long m = __ballot(pred);
-            if (pred) ctag[running + __popcll(m & ((1ull << lane) - 1ull))] = (slot << TAG_PID_BITS) | pid;
+            if (pred) {
+                const unsigned at = running + __popcll(m & ((1ull << lane) - 1ull));
+                const int tag = (slot << TAG_PID_BITS) | pid;
+                if (WRITE_DIR) {
+                    // the direction conn_ray() tested in pass 1 (trace.metal:580 / :684), and the one ConnRaySource would rebuild
+                    const V3 dir = normalize(target - lv[s - 1].o);
+                    cdir[at] = f4(dir, __int_as_float(tag));
+                } else {
+                    ctag[at] = tag;
+                }
+            }
             running += __popcll(m);
         }
     }
@@ -1051,6 +1114,31 @@ __global__ __launch_bounds__(BLOCK) void k_finalize(int B, int W, int H, const f
     }
     finalized[id] = make_float4(total.x, total.y, total.z, 1.0f);
     sample_w[id] = wsum;
+}
+
+// ---------------------------------------------------------------- reproducible light image (det_splat.hpp)
+// `sorted`: the n record keys of one pass in ascending order = by (target entry, s, source pixel); slots without a
+// contribution hold DET_NO_KEY and sort to the end.  The thread that finds the FIRST key of a target sums that target's run
+// front to back and adds it to the light image: one writer per pixel, one order.  Runs are short (<= 6 contributions per source
+// pixel, spread over the film).
+__global__ __launch_bounds__(BLOCK) void k_det_gather(const unsigned long long* __restrict__ sorted, size_t n,
+                                                      const float4* __restrict__ vals, float4* __restrict__ light_image) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = sorted[i];
+    if (k == ~0ull) return;
+    const unsigned pix = (unsigned)(k >> 32);
+    if (i > 0 && (unsigned)(sorted[i - 1] >> 32) == pix) return;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (size_t j = i; j < n; j++) {
+        const unsigned long long kj = sorted[j];
+        if ((unsigned)(kj >> 32) != pix) break;                       // the next target, or the first empty slot
+        const float4 v = vals[(unsigned)kj];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float4 l = light_image[pix];
+    l.x += acc.x; l.y += acc.y; l.z += acc.z; l.w += acc.w;
+    light_image[pix] = l;
 }
 
 __device__ __forceinline__ float scrub(float x) {   // np.nan_to_num(x, posinf=0, neginf=0)

@@ -20,6 +20,7 @@
 #include "../../include/clive2_amd.h"
 #include "kernels.hpp"
 #include "tonemap.hpp"
+#include "det_splat.hpp"
 #include "bvh_builder.hpp"
 #include "comm_rccl.hpp"
 #include "comm_wait.hpp"
@@ -60,7 +61,8 @@ struct cl2_renderer {
     int paths_share = 0;                 // eighths of the wave slots given to the subpath stage while pipelining (0 = not tuned yet)
     int pipelining = -1;                 // sample pipeline inside cl2_run_samples: 0 serial, 1 two stages, 2 three stages, -1 by frame size
     std::string err;
-    bool scene_ok = false, counting = false;
+    bool scene_ok = false;
+    int counting = 0;                    // 0 off, 1 the reference walk's node / triangle tallies (binary walk), 2 the 4-wide walk's own tallies
     int profiling = 0;                   // 0 off, 1 the connection-ray traversal launch only, 2 every stage
     int debug_flags = 0;
     int gather_lanes = 32, gather_wait = 48;   // whole-subpath launch: lanes gathered / steps waited before a wave runs its bounce phase
@@ -98,6 +100,13 @@ struct cl2_renderer {
     int* d_queue = nullptr;            // [6][B], shared by both subpath kinds (they run one after the other)
     unsigned* d_qcount = nullptr;      // [9]: [0] = B (level-0 count), [1..6] level counts, [7] connection rays, [8] = 2B
     int* d_ctag = nullptr;             // connection-ray queue: {slot, pixel} tags
+    float4* d_cdir = nullptr;          // connection-ray queue of the persistent walks: {direction, tag} (ConnDirRaySource); allocated on first use
+    // reproducible light image (cl2_set_reproducible, det_splat.hpp): records of one pass, allocated on first use
+    bool reproducible = false;
+    unsigned long long *d_det_keys = nullptr, *d_det_sorted = nullptr;
+    float4* d_det_vals = nullptr;
+    void* d_det_tmp = nullptr;
+    size_t det_tmp_bytes = 0;
     float2* d_chit[2] = {nullptr, nullptr};            // two sets: connection rays of sample i+1 vs resolve of sample i
     unsigned long long* d_cmask[2] = {nullptr, nullptr};
     float* d_agg = nullptr;
@@ -177,7 +186,8 @@ hipEvent_t take_event(cl2_renderer* r) {
 struct Timed {   // records a HIP-event span around a launch when profiling is on
     cl2_renderer* r; int stage; hipStream_t st; hipEvent_t a = nullptr;
     Timed(cl2_renderer* r_, int stage_, hipStream_t st_) : r(r_), stage(stage_), st(st_) {
-        const bool wanted = r->profiling >= 2 || (r->profiling == 1 && stage == ST_TRAVERSE_CONN);
+        // level 1: the two traversal stages only (the connection-ray launch and the subpath traversal launches: bench.py's rooflines)
+        const bool wanted = r->profiling >= 2 || (r->profiling == 1 && (stage == ST_TRAVERSE_CONN || stage == ST_TRAVERSE_PATHS));
         if (wanted) {
             a = take_event(r);
             if (a && hipEventRecord(a, st) != hipSuccess) { r->event_pool.push_back(a); a = nullptr; }
@@ -240,6 +250,9 @@ int launch_generate_both(cl2_renderer* r, hipStream_t st, const PathBufs* set) {
 inline size_t bvh_lds_bytes(const cl2_renderer* r) {
     return ((size_t)2 * r->bvh.n_lds_nodes + (r->bvh.lds_tris ? (size_t)3 * r->bvh.n_tris : 0) + (size_t)2 * r->bvh.n_fast_nodes) * sizeof(float4);
 }
+// counting mode 1: the node / triangle tallies of the REFERENCE's walk (binary stackless walk; the wide walk steps aside);
+// mode 2 tallies what the 4-wide walk itself fetches and changes no launch but the whole-subpath one (see whole_subpaths)
+inline bool count_ref(const cl2_renderer* r) { return r->counting == 1; }
 inline bool tree_in_lds(const cl2_renderer* r) { return r->bvh.lds_tris && r->bvh.n_nodes <= r->bvh.n_lds_nodes; }
 inline bool split_paths(const cl2_renderer* r) {
     if (r->traversal_mode == 1 || r->traversal_mode == 3) return false;
@@ -255,7 +268,7 @@ inline bool split_conn(const cl2_renderer* r) {
 // the gathered refill the wide walk is ahead there too (round 3, same box: connection launch 14.08 -> 13.51 ms, sample 27.78 ->
 // 27.22 ms).  Never while counting: the node-test tallies are defined by the binary walk.
 inline bool wide_walk(const cl2_renderer* r) {
-    if (r->n_wide <= 0 || r->counting) return false;
+    if (r->n_wide <= 0 || count_ref(r)) return false;
     if (r->traversal_mode == 5) return true;
     return (r->traversal_mode == 0 || r->traversal_mode == 3 || r->traversal_mode == 4) && !tree_in_lds(r);
 }
@@ -269,6 +282,7 @@ inline bool wide_walk(const cl2_renderer* r) {
 // lose: there the per-level form wins in serial order too (interior 4K: 53.7 vs 61.6 ms of subpath time, blob 24.0 vs
 // 28.1).  So the automatic choice takes it in the serial order and up to 2^22 pixels only.
 inline bool whole_subpaths(const cl2_renderer* r) {
+    if (r->counting == 2 && r->traversal_mode != 4) return false;   // the walk's own tallies are taken in k_traverse_wide: every ray goes through it
     return r->traversal_mode == 4 || (r->traversal_mode == 0 && !tree_in_lds(r) && !r->pipe_active && r->B <= (1 << 22));
 }
 // Two triangles per step of the persistent walk while the tree is cache-resident (the step is then
@@ -356,10 +370,11 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
     // the binary records (lanes whose ray has a non-finite 1/d) come through the caches: no window for them
     BvhView b = r->bvh;
     b.n_lds_nodes = 0; b.lds_tris = 0; b.n_fast_nodes = 0;
-    if (streams_from_memory)
-        hipLaunchKernelGGL((k_traverse_wide<1, Source>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn);
-    else
-        hipLaunchKernelGGL((k_traverse_wide<WIDE_TRI_REPS, Source>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn);
+#define CL2_WIDE(REPS, TALLY) \
+    hipLaunchKernelGGL((k_traverse_wide<REPS, Source, TALLY>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
+    if (streams_from_memory) { if (r->counting == 2) CL2_WIDE(1, true); else CL2_WIDE(1, false); }
+    else { if (r->counting == 2) CL2_WIDE(WIDE_TRI_REPS, true); else CL2_WIDE(WIDE_TRI_REPS, false); }
+#undef CL2_WIDE
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;
 }
@@ -406,8 +421,8 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
                                st, r->bvh, c_trav, r->d_work + first * WORK_STRIDE, SRC, r->d_stats, 0)
 #define CL2_PERSIST_SRC(SRCT, SRC)                                                                                         \
             do {                                                                                                           \
-                if (two_tris_per_step(r)) { if (r->counting) CL2_PERSIST(true, true, SRCT, SRC); else CL2_PERSIST(false, true, SRCT, SRC); } \
-                else { if (r->counting) CL2_PERSIST(true, false, SRCT, SRC); else CL2_PERSIST(false, false, SRCT, SRC); }       \
+                if (two_tris_per_step(r)) { if (count_ref(r)) CL2_PERSIST(true, true, SRCT, SRC); else CL2_PERSIST(false, true, SRCT, SRC); } \
+                else { if (count_ref(r)) CL2_PERSIST(true, false, SRCT, SRC); else CL2_PERSIST(false, false, SRCT, SRC); }       \
             } while (0)
             if (merged) CL2_PERSIST_SRC(DualPathRaySource, dual); else CL2_PERSIST_SRC(PathRaySource, src);
 #undef CL2_PERSIST_SRC
@@ -423,8 +438,8 @@ int launch_trace(cl2_renderer* r, int which, hipStream_t st, const PathBufs* set
                            first, end, q_in, c_in, q_out, c_out, B, pb, r->d_seeds, r->d_tri_shade, r->d_mats, r->n_mats,        \
                            r->d_block_stats, ext_hit)
         if (split) { if (which == CL2_CAMERA) CL2_TRACE(true, false, true); else CL2_TRACE(false, false, true); }
-        else if (which == CL2_CAMERA) { if (r->counting) CL2_TRACE(true, true, false); else CL2_TRACE(true, false, false); }
-        else { if (r->counting) CL2_TRACE(false, true, false); else CL2_TRACE(false, false, false); }
+        else if (which == CL2_CAMERA) { if (count_ref(r)) CL2_TRACE(true, true, false); else CL2_TRACE(true, false, false); }
+        else { if (count_ref(r)) CL2_TRACE(false, true, false); else CL2_TRACE(false, false, false); }
 #undef CL2_TRACE
         if (!split) r->launches_tp++;
         HIP_TRY(r, hipGetLastError());
@@ -467,8 +482,8 @@ int launch_subpaths(cl2_renderer* r, hipStream_t st, const PathBufs* set, int ki
                        r->B, r->d_work, set[CL2_LIGHT], set[CL2_CAMERA], r->d_seeds, r->d_tri_shade, r->d_mats, r->n_mats, \
                        r->d_stats, lanes, wait, kinds)
     if (widew) { if (two_tris_per_step(r)) CL2_WHOLE(false, true, true, WIDE_TRI_REPS); else CL2_WHOLE(false, true, true, 1); }
-    else if (two_tris_per_step(r)) { if (r->counting) CL2_WHOLE(true, true, false); else CL2_WHOLE(false, true, false); }
-    else { if (r->counting) CL2_WHOLE(true, false, false); else CL2_WHOLE(false, false, false); }
+    else if (two_tris_per_step(r)) { if (count_ref(r)) CL2_WHOLE(true, true, false); else CL2_WHOLE(false, true, false); }
+    else { if (count_ref(r)) CL2_WHOLE(true, false, false); else CL2_WHOLE(false, false, false); }
 #undef CL2_WHOLE
     r->launches_tp++;
     HIP_TRY(r, hipGetLastError());
@@ -481,6 +496,9 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
     const PathBufs& lp = set[CL2_LIGHT];
     const PathBufs& cp = set[CL2_CAMERA];
     HIP_TRY(r, hipMemsetAsync(r->d_qcount + 7, 0, sizeof(unsigned), st));
+    // the persistent walks take their rays' directions from the queue ({direction, tag}, written by the set-up kernel:
+    // ConnDirRaySource); debug bit 13 keeps round 4's form (4-byte tags, the ray rebuilt from its two vertices) for A/B runs
+    const bool dir_queue = split_conn(r) && !((r->debug_flags >> 13) & 1);
     {
         Timed t(r, ST_CONNECT_SETUP, st);
         // Large scenes: this launch (8,100 short workgroups at 7 waves per SIMD) runs beside the persistent subpath launches of
@@ -489,8 +507,14 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
         // -> 10.85 (25 KB: 8.71 / 11.08; 31 KB: 8.44 / 10.98; 52 KB: 8.61 / 10.86).  The Cornell pipeline has no persistent
         // launches and wants the kernel at full speed.
         const size_t pad = split_conn(r) ? (size_t)39 * 1024 : 0;
-        hipLaunchKernelGGL(k_connect_setup, dim3(grid_for(B)), dim3(BLOCK), pad, st, B, lp, cp,
-                           r->d_mats, r->n_mats, r->cam, r->d_ctag, r->d_qcount + 7, r->d_cmask[cs]);
+        if (dir_queue) {
+            if (!r->d_cdir) TRY(dev_alloc(r, &r->d_cdir, (size_t)CONN_SLOTS * B));
+            hipLaunchKernelGGL(k_connect_setup<true>, dim3(grid_for(B)), dim3(BLOCK), pad, st, B, lp, cp,
+                               r->d_mats, r->n_mats, r->cam, r->d_ctag, r->d_cdir, r->d_qcount + 7, r->d_cmask[cs]);
+        } else {
+            hipLaunchKernelGGL(k_connect_setup<false>, dim3(grid_for(B)), dim3(BLOCK), pad, st, B, lp, cp,
+                               r->d_mats, r->n_mats, r->cam, r->d_ctag, (float4*)nullptr, r->d_qcount + 7, r->d_cmask[cs]);
+        }
     }
     HIP_TRY(r, hipGetLastError());
     {
@@ -499,20 +523,27 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
             HIP_TRY(r, hipMemsetAsync(r->d_work + 7 * WORK_STRIDE, 0, WORK_STRIDE * sizeof(unsigned), st));
             ConnRaySource src{r->d_ctag, lp.P0, cp.P0, r->d_chit[cs],
                               V3{r->cam.focal_point[0], r->cam.focal_point[1], r->cam.focal_point[2]}, B};
+            ConnDirRaySource dsrc{r->d_cdir, lp.P0, r->d_chit[cs], B};
             if (wide_walk(r)) {
-                TRY(launch_wide(r, st, 1, r->d_qcount + 7, r->d_work + 7 * WORK_STRIDE, src, 1));
+                if (dir_queue) TRY(launch_wide(r, st, 1, r->d_qcount + 7, r->d_work + 7 * WORK_STRIDE, dsrc, 1));
+                else TRY(launch_wide(r, st, 1, r->d_qcount + 7, r->d_work + 7 * WORK_STRIDE, src, 1));
             } else {
-#define CL2_PERSIST(CNT, TWO)                                                                                             \
-            hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, ConnRaySource>), dim3(persistent_grid_conn(r)), dim3(BLOCK), bvh_lds_bytes(r), \
-                               st, r->bvh, r->d_qcount + 7, r->d_work + 7 * WORK_STRIDE, src, r->d_stats, 1)
-            if (two_tris_per_step(r)) { if (r->counting) CL2_PERSIST(true, true); else CL2_PERSIST(false, true); }
-            else { if (r->counting) CL2_PERSIST(true, false); else CL2_PERSIST(false, false); }
+#define CL2_PERSIST(CNT, TWO, SRCT, SRC)                                                                                  \
+            hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, SRCT>), dim3(persistent_grid_conn(r)), dim3(BLOCK), bvh_lds_bytes(r), \
+                               st, r->bvh, r->d_qcount + 7, r->d_work + 7 * WORK_STRIDE, SRC, r->d_stats, 1)
+#define CL2_PERSIST_SRC(SRCT, SRC)                                                                                        \
+            do {                                                                                                          \
+                if (two_tris_per_step(r)) { if (count_ref(r)) CL2_PERSIST(true, true, SRCT, SRC); else CL2_PERSIST(false, true, SRCT, SRC); } \
+                else { if (count_ref(r)) CL2_PERSIST(true, false, SRCT, SRC); else CL2_PERSIST(false, false, SRCT, SRC); }      \
+            } while (0)
+            if (dir_queue) CL2_PERSIST_SRC(ConnDirRaySource, dsrc); else CL2_PERSIST_SRC(ConnRaySource, src);
+#undef CL2_PERSIST_SRC
 #undef CL2_PERSIST
             }
         } else {
             // grid-stride over the (device-side) ray count; enough workgroups to fill 256 CUs several times over
             const int grid = std::min<size_t>(grid_for((size_t)B * 8), 256 * 32);
-            if (r->counting)
+            if (count_ref(r))
                 hipLaunchKernelGGL(k_traverse_conn<true>, dim3(grid), dim3(BLOCK), bvh_lds_bytes(r), st, r->bvh, B, r->d_qcount + 7, r->d_ctag,
                                    lp.P0, cp.P0, r->cam, r->d_chit[cs], r->d_stats);
             else
@@ -525,15 +556,31 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
     return CL2_OK;
 }
 
+// buffers of the reproducible light image: one record slot per (light vertex, entry), as the reference's five arrays
+int ensure_det_buffers(cl2_renderer* r) {
+    if (r->d_det_keys) return CL2_OK;
+    const size_t n = (size_t)MAX_VERTS * r->B;
+    TRY(dev_alloc(r, &r->d_det_keys, n));
+    TRY(dev_alloc(r, &r->d_det_sorted, n));
+    TRY(dev_alloc(r, &r->d_det_vals, n));
+    size_t bytes = 0;
+    HIP_TRY(r, det_sort_keys(nullptr, bytes, r->d_det_keys, r->d_det_sorted, n, r->stream));
+    unsigned char* tmp = nullptr;
+    TRY(dev_alloc(r, &tmp, bytes));
+    r->d_det_tmp = tmp; r->det_tmp_bytes = bytes;
+    return CL2_OK;
+}
+
 int launch_resolve(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs) {
     const int B = r->B;
     const PathBufs& lp = set[CL2_LIGHT];
     const PathBufs& cp = set[CL2_CAMERA];
     {
         Timed t(r, ST_CONNECT_RESOLVE, st);
-#define CL2_RESOLVE(W, ML)                                                                                                       \
-        hipLaunchKernelGGL((k_connect_resolve<W, ML>), dim3(grid_for(B)), dim3(BLOCK), 0, st, B, lp, cp, r->d_mats, r->n_mats, r->d_tri_shade,   \
-                           r->cam_tris, r->cam, r->d_cmask[cs], r->d_chit[cs], r->d_agg, r->d_light_image, r->d_uni, r->d_stats, r->debug_flags)
+#define CL2_RESOLVE(W, ML, DET)                                                                                                  \
+        hipLaunchKernelGGL((k_connect_resolve<W, ML, DET>), dim3(grid_for(B)), dim3(BLOCK), 0, st, B, lp, cp, r->d_mats, r->n_mats, r->d_tri_shade, \
+                           r->cam_tris, r->cam, r->d_cmask[cs], r->d_chit[cs], r->d_agg, r->d_light_image, r->d_uni, r->d_stats, r->debug_flags, \
+                           r->d_det_keys, r->d_det_vals)
         // 3 waves per SIMD: what 165 VGPRs and 52 KB of LDS tables per workgroup allow (2 / 4 measured slower: DESIGN 6.1).  Debug
         // bits 4-6 = 7: one wave per camera vertex (tests/connect_resolve_wide.hpp: same results bit for bit, measured slower: 1.14 vs
         // 0.93 ms; a second implementation kept as a cross-check, built only with -DCL2_TEST_VARIANT = libclive2_amd_test.so)
@@ -550,10 +597,28 @@ int launch_resolve(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
         if (occ == 7) return fail(r, CL2_E_INVALID, "the one-wave-per-camera-vertex resolve kernel is only built into the test variant of the library");
 #endif
         // the material table goes to LDS when it fits LDS_MAT_CAP entries (the reference ships 8): connect_resolve.hpp
-        if (r->n_mats <= LDS_MAT_CAP) CL2_RESOLVE(3, true); else CL2_RESOLVE(3, false);
+        if (r->reproducible) {
+            // records instead of atomics: every slot starts empty (DET_NO_KEY = all ones)
+            TRY(ensure_det_buffers(r));
+            HIP_TRY(r, hipMemsetAsync(r->d_det_keys, 0xFF, (size_t)MAX_VERTS * B * sizeof(unsigned long long), st));
+            if (r->n_mats <= LDS_MAT_CAP) CL2_RESOLVE(2, true, true); else CL2_RESOLVE(2, false, true);      // the record stores need registers the 168 of three waves do not leave
+        } else {
+            // (more than LDS_MAT_CAP materials: the table stays in global memory and its addresses take the registers that three
+            // waves per SIMD do not leave -- two waves, no scratch)
+            if (r->n_mats <= LDS_MAT_CAP) CL2_RESOLVE(3, true, false); else CL2_RESOLVE(2, false, false);
+        }
 #undef CL2_RESOLVE
     }
     HIP_TRY(r, hipGetLastError());
+    if (r->reproducible) {
+        // order the records by (target entry, s, source pixel), then one thread per target sums its run front to back
+        Timed t(r, ST_CONNECT_RESOLVE, st);
+        const size_t n = (size_t)MAX_VERTS * B;
+        size_t bytes = r->det_tmp_bytes;
+        HIP_TRY(r, det_sort_keys(r->d_det_tmp, bytes, r->d_det_keys, r->d_det_sorted, n, st));
+        hipLaunchKernelGGL(k_det_gather, dim3(grid_for(n)), dim3(BLOCK), 0, st, r->d_det_sorted, n, r->d_det_vals, r->d_light_image);
+        HIP_TRY(r, hipGetLastError());
+    }
     return CL2_OK;
 }
 
@@ -600,6 +665,9 @@ void free_pixel_state(cl2_renderer* r) {
             dev_free(r, pb.tri); dev_free(r, pb.len); dev_free(r, pb.carry);
         }
     dev_free(r, r->d_hit); dev_free(r, r->d_hit_cam0); dev_free(r, r->d_queue); dev_free(r, r->d_ctag);
+    dev_free(r, r->d_cdir);
+    dev_free(r, r->d_det_keys); dev_free(r, r->d_det_sorted); dev_free(r, r->d_det_vals); dev_free(r, r->d_det_tmp);
+    r->det_tmp_bytes = 0;
     for (int q = 0; q < 2; q++) { dev_free(r, r->d_chit[q]); dev_free(r, r->d_cmask[q]); }
     dev_free(r, r->d_agg); dev_free(r, r->d_light_image); dev_free(r, r->d_finalized); dev_free(r, r->d_uni);
     dev_free(r, r->d_sample_w); dev_free(r, r->d_block_stats);
@@ -1733,6 +1801,20 @@ int cl2_set_debug_flags(cl2_renderer* r, int flags) {
     r->bvh.fast_flat = ((flags >> 11) & 1) ? 0 : r->fast_flat;     // bit 11: per-lane walk of a flat pruned table (A/B of the wave-uniform one)
     return CL2_OK;
 }
+/* Reproducible light image (off by default): the t = 1 contributions are written as records, sorted by (target pixel, s, source
+ * pixel) and summed per target in that order (det_splat.hpp) instead of being added with float atomics in whatever order the
+ * hardware serves them.  Two renders of the same scene and seeds then give the same bytes in all four accumulators -- as the
+ * reference's sort + bincount + gather chain does (src/renderer.py:97-111, :213-250).  Costs a radix sort of 6 x W x H keys per
+ * pass and 32 bytes of record space per slot. */
+int cl2_set_reproducible(cl2_renderer* r, int on) {
+    if (!r) return CL2_E_INVALID;
+    HIP_TRY(r, hipSetDevice(r->device));
+    TRY(drain(r));
+    r->reproducible = on != 0;
+    return CL2_OK;
+}
+int cl2_get_reproducible(const cl2_renderer* r) { return r ? (r->reproducible ? 1 : 0) : CL2_E_INVALID; }
+
 int cl2_set_subpath_gather(cl2_renderer* r, int lanes, int wait_steps) {
     if (!r) return CL2_E_INVALID;
     if (lanes < 0 || lanes > 64 || wait_steps < 0 || wait_steps > 1000) return fail(r, CL2_E_INVALID, "subpath gather: 0..64 lanes (0 = default 32), 0..1000 steps (0 = default 48)");
@@ -1751,7 +1833,27 @@ int cl2_walk_histo(cl2_renderer* r, unsigned long long* out) {
     return CL2_OK;
 }
 #endif
-int cl2_set_counting(cl2_renderer* r, int on) { if (!r) return CL2_E_INVALID; r->counting = on != 0; return CL2_OK; }
+int cl2_set_counting(cl2_renderer* r, int mode) {
+    if (!r) return CL2_E_INVALID;
+    if (mode < 0 || mode > 2) return fail(r, CL2_E_INVALID, "counting: 0 off, 1 the reference walk's tallies (binary walk), 2 the 4-wide walk's own tallies");
+    r->counting = mode;
+    return CL2_OK;
+}
+
+/* cl2_set_counting(2): what the 4-wide walk itself fetched since the last cl2_reset_counters -- rays, wide nodes visited, distinct
+ * triangle records read, stack entries spilled to the global overflow array, binary records visited by rays with a non-finite
+ * 1/d -- separately for the subpath launches and the connection launch.  Zero where the scene does not take the wide walk. */
+int cl2_read_walk_tallies(cl2_renderer* r, cl2_walk_tallies* out) {
+    if (!r || !out) return CL2_E_INVALID;
+    HIP_TRY(r, hipSetDevice(r->device));
+    TRY(drain(r));
+    Stats s;
+    HIP_TRY(r, hipMemcpy(&s, r->d_stats, sizeof s, hipMemcpyDeviceToHost));
+    static_assert(sizeof(out->subpath) == sizeof(s.walk[0]) && sizeof(out->connection) == sizeof(s.walk[1]), "tally layout");
+    std::memcpy(&out->subpath, s.walk[0], sizeof s.walk[0]);
+    std::memcpy(&out->connection, s.walk[1], sizeof s.walk[1]);
+    return CL2_OK;
+}
 
 int cl2_read_counters(cl2_renderer* r, cl2_counters* out) {
     if (!r || !out) return CL2_E_INVALID;
@@ -1873,7 +1975,7 @@ int cl2_probe_traverse(cl2_renderer* r, const void* rays_v, size_t n_rays, int32
                   hipMemcpy(d_n, &n, sizeof n, hipMemcpyHostToDevice) == hipSuccess;
         if (!ok) rc = fail(r, CL2_E_HIP, "probe upload failed");
     }
-    if (rc == CL2_OK && r->traversal_mode == 5 && r->n_wide > 0 && !r->counting) {
+    if (rc == CL2_OK && r->traversal_mode == 5 && r->n_wide > 0 && !count_ref(r)) {
         // the probe through the exact 4-wide walk (rays with a non-finite 1/d take the binary walk inside it)
         if (hipMemsetAsync(r->d_work, 0, WORK_STRIDE * sizeof(unsigned), r->stream) != hipSuccess) rc = fail(r, CL2_E_HIP, "probe memset failed");
         if (rc == CL2_OK) {
@@ -1882,7 +1984,7 @@ int cl2_probe_traverse(cl2_renderer* r, const void* rays_v, size_t n_rays, int32
             if (rc == CL2_OK) rc = drain(r);
         }
     } else if (rc == CL2_OK) {
-        if (r->counting)
+        if (count_ref(r))
             hipLaunchKernelGGL(k_traverse_paths<true>, dim3(grid_for(n_rays)), dim3(BLOCK), bvh_lds_bytes(r), r->stream, r->bvh, (const int*)nullptr, d_n, d_o, d_d, d_h, r->d_stats);
         else
             hipLaunchKernelGGL(k_traverse_paths<false>, dim3(grid_for(n_rays)), dim3(BLOCK), bvh_lds_bytes(r), r->stream, r->bvh, (const int*)nullptr, d_n, d_o, d_d, d_h, r->d_stats);

@@ -143,19 +143,6 @@ def samples_for_rank(total_samples, rank, world_size):
     return base + (1 if rank < extra else 0)
 
 
-def allreduce_packed_host(packed, group=None):
-    """CPU-side rehearsal of the reduce for tests (tests/test_distributed_cpu.py: world_size-2 gloo
-    group, the oracle standing in for the GPU): sums a packed accumulator array over a
-    torch.distributed group through host memory.  The GPU path does not come here: it is
-    `Renderer.reduce_accumulators` (RCCL inside the library).  Returns a new float32 numpy array."""
-    import torch
-    import torch.distributed as dist
-    t = torch.from_numpy(np.ascontiguousarray(packed, dtype=np.float32).copy())
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return t.numpy()
-
-
 def radiance_from_packed(packed, height, width):
     """`summed_image / summed_sample_weights` (renderer.py:295-297) from the packed planar buffer."""
     a = np.asarray(packed, dtype=np.float32).reshape(8, height, width)

@@ -313,7 +313,16 @@ class Renderer:
         self._check(self._L.cl2_set_profiling(self._h, level), "set_profiling")
 
     def set_counting(self, on=True):
-        self._check(self._L.cl2_set_counting(self._h, int(bool(on))), "set_counting")
+        """True / 1: the node and triangle test tallies of the reference's walk (counters()); 2: what the 4-wide walk itself
+        fetches (walk_tallies()); False / 0: off."""
+        self._check(self._L.cl2_set_counting(self._h, int(on)), "set_counting")
+
+    def walk_tallies(self):
+        """{'subpath': {...}, 'connection': {...}} of set_counting(2): rays, wide nodes visited, triangle records read, stack
+        entries spilled to global memory, binary records (rays with a non-finite 1/d) since the last reset_counters()."""
+        t = _native.WalkTallies()
+        self._check(self._L.cl2_read_walk_tallies(self._h, C.byref(t)), "read_walk_tallies")
+        return {k: {n: getattr(getattr(t, k), n) for n, _ in _native.WalkTally._fields_} for k in ("subpath", "connection")}
 
     def set_levels_per_launch(self, levels):
         """Bounces traced per launch (1..6, 0 = chosen from the survival seen in the first sample); a pure
@@ -342,6 +351,12 @@ class Renderer:
         """Launch-organisation switches (include/clive2_amd.h); none changes a result.  The shipped library
         refuses bits 0-2 (they skip parts of the resolve stage and exist only in the test variant)."""
         self._check(self._L.cl2_set_debug_flags(self._h, int(flags)), "set_debug_flags")
+
+    def set_reproducible(self, on=True):
+        """Reproducible light image (cl2_set_reproducible): the t = 1 contributions sorted and summed in a fixed order instead of
+        float atomics -- two renders of the same scene and seeds then agree byte for byte, as the reference's sort + gather
+        chain does (renderer.py:97-111, :213-250).  Off by default (costs a radix sort per pass)."""
+        self._check(self._L.cl2_set_reproducible(self._h, int(bool(on))), "set_reproducible")
 
     def set_subpath_gather(self, lanes=0, wait_steps=0):
         """Whole-subpath launch: lanes gathered / steps waited before a wave runs its bounce phase (0 = default)."""

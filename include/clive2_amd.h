@@ -261,9 +261,18 @@ typedef struct {
 int cl2_query_organisation(cl2_renderer* r, cl2_organisation* out);
 
 /* -- counters / profiling -- */
-int cl2_set_profiling(cl2_renderer* r, int level);  /* HIP-event timers: 0 off, 1 the connection-ray traversal launch only, 2 every stage */
-int cl2_set_counting(cl2_renderer* r, int on);      /* node / triangle test tallies in the traversal kernels */
+int cl2_set_profiling(cl2_renderer* r, int level);  /* HIP-event timers: 0 off, 1 the traversal launches only (connection rays, subpath rays), 2 every stage */
+/* mode 1: node / triangle test tallies of the REFERENCE's walk (src/trace.metal:144-176; the traversal kernels then run the
+ * binary stackless walk, whose tests are the reference's one for one) -> cl2_counters.box_tests / tri_tests / counted_rays.
+ * mode 2: what the exact 4-wide walk ITSELF fetches -> cl2_read_walk_tallies (the launches are the ones that run uncounted,
+ * except that single run_sample() calls take the per-level organisation).  0: off. */
+int cl2_set_counting(cl2_renderer* r, int mode);
 int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
+typedef struct cl2_walk_tally {
+    uint64_t rays, wide_visits, tri_records, stack_spills, binary_records;
+} cl2_walk_tally;
+typedef struct cl2_walk_tallies { cl2_walk_tally subpath, connection; } cl2_walk_tallies;
+int cl2_read_walk_tallies(cl2_renderer* r, cl2_walk_tallies* out);
 /* Launch-organisation switches for experiments and tests.  None of them changes a result.
  *   bit 3       accepted and ignored (rounds 2-3: the per-level subpath launches took the 4-wide walk in the serial order too; they
  *               always do since round 4)
@@ -274,6 +283,8 @@ int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
  *   bit 11      walk a pruned table that is a plain list of leaves per lane instead of wave-uniformly (csrc/bvh_traverse.hpp,
  *               closest_hit_flat)
  *   bit 12      invert the one/two-triangles-per-step choice of the persistent walk
+ *   bit 13      connection-ray queue of the persistent walks as 4-byte tags (the ray rebuilt from its two vertices, round 4)
+ *               instead of {direction, tag} written by the set-up kernel (round 5)
  *   bits 16-19  accepted and ignored (round 3: stack entries per lane in LDS of the 4-wide walk; a compile-time 8 since round 4)
  *   bits 20-23  4-wide walk: LDS window of the top of the wide tree in units of 32 nodes (0 = by tree size: 32 nodes, 64 when
  *               the tree streams from memory; 15 = no window)
@@ -281,8 +292,15 @@ int cl2_read_counters(cl2_renderer* r, cl2_counters* out);
  * (libclive2_amd_test.so, -DCL2_TEST_VARIANT), where they switch parts of the resolve stage off for timing
  * dissections -- bit 0 the t = 1 splat atomics, bit 1 / bit 2 the t >= 2 / t == 1 strategy pairs -- and make the
  * render INVALID; the shipped library refuses them. */
-#define CL2_DEBUG_KNOWN_BITS 0x00FF1FFF
+#define CL2_DEBUG_KNOWN_BITS 0x00FF3FFF
 int cl2_set_debug_flags(cl2_renderer* r, int flags);
+/* Reproducible light image, off by default.  The reference's light-image chain (sort by target pixel, per-pixel gather:
+ * src/renderer.py:97-111, :213-250, src/trace.metal:872-964) is deterministic; the float atomics that replace it add a pixel's
+ * contributions in hardware order, so two renders agree to a few ulp only.  on = 1: k_connect_resolve writes the reference's
+ * records (slot id + s * total_pixels), one radix sort orders them by (target pixel, s, source pixel) and each target's run is
+ * summed front to back -- two renders of the same scene and seeds give identical bytes in all four accumulators. */
+int cl2_set_reproducible(cl2_renderer* r, int on);
+int cl2_get_reproducible(const cl2_renderer* r);
 /* Whole-subpath launch (traversal mode 4): lanes that must have gathered with a known closest hit before a wave runs
  * its bounce phase, and the steps the first of them waits at most.  0 = default (32 lanes, 48 steps).  Same results. */
 int cl2_set_subpath_gather(cl2_renderer* r, int lanes, int wait_steps);

@@ -230,8 +230,17 @@ class OracleRenderer:
         offset = np.sum(idx < 0).astype(np.uint32)
         return summed, offset
 
-    def gather_light_image(self):
-        self.L.orc_light_sort_all(*self._light_arrays(), C.c_uint32(self.n_light))
+    def gather_light_image(self, stable=False):
+        """renderer.py:212-250.  `stable=True` (tests of the product's reproducible light image): the five arrays are ordered
+        by a STABLE sort on the pixel key instead of the reference's bitonic network, i.e. a pixel's run keeps slot order
+        `id + s * total_pixels` = by (s, source pixel); bins and K8 (trace.metal:937-964) are unchanged."""
+        if stable:
+            order = np.argsort(self.out_light_indices, kind="stable")
+            for a in (self.out_light_indices, self.out_light_path_indices, self.out_light_ray_indices,
+                      self.out_light_weights, self.out_light_shade):
+                a[:] = a[order]
+        else:
+            self.L.orc_light_sort_all(*self._light_arrays(), C.c_uint32(self.n_light))
         bins, offset = self.light_bins()
         bins = np.ascontiguousarray(bins.astype(np.int32))
         self.L.orc_light_image_gather(C.c_int(self.batch_size), _p(self.out_light_paths), _p(self.materials),
@@ -251,14 +260,14 @@ class OracleRenderer:
         uni = self.out_camera_image.reshape(H, W, 4)[:, :, :3]
         self.unidirectional_image_buffer += np.nan_to_num(uni, posinf=0, neginf=0)
 
-    def run_sample(self):
+    def run_sample(self, stable_light_sort=False):
         self.make_light_rays()
         self.make_camera_rays()
         self.trace_light_rays()
         self.trace_camera_rays()
         self.join_paths()
         self.finalize_samples()
-        self.gather_light_image()
+        self.gather_light_image(stable=stable_light_sort)
         self.process_images()
         self.samples += 1
 

@@ -1,7 +1,8 @@
 """N > 1 path on CPU: world_size-2 gloo process group.  Each rank integrates its own samples
 (own seed buffer) -- here with the oracle standing in for the GPU -- and the packed accumulators
-are summed with the product's all-reduce helper; the result must equal the single-process sum and
-the radiance of the combined run (accumulators are pure sums)."""
+are summed over the group through host memory (the GPU path is `Renderer.reduce_accumulators`: RCCL inside
+the library); the result must equal the single-process sum and the radiance of the combined run
+(accumulators are pure sums)."""
 import os
 import socket
 import sys
@@ -34,12 +35,23 @@ def _render_rank(rank):
     return _packed_from_oracle(o)
 
 
+def allreduce_packed_host(packed, group=None):
+    """CPU-side rehearsal of the reduce (test code: torch.distributed / gloo stands in for RCCL): sums a packed
+    accumulator array over the group through host memory.  Returns a new float32 numpy array."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(packed, dtype=np.float32).copy())
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.numpy()
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank), OMP_NUM_THREADS="2")
     import torch.distributed as dist
-    from clive2_amd.distributed import allreduce_packed_host, rank_info
+    from clive2_amd.distributed import rank_info
     dist.init_process_group("gloo", rank=rank, world_size=world)
     assert rank_info() == (rank, rank, world)
     total = allreduce_packed_host(_render_rank(rank))

@@ -240,6 +240,38 @@ def test_light_sort_gather_equals_direct_splat(oracle_mod):
     assert (np.diff(o.out_light_indices) >= 0).all()      # bitonic network sorted the keys
 
 
+def test_stable_light_order_is_the_same_chain_in_slot_order(oracle_mod):
+    """`gather_light_image(stable=True)` (the order of the product's reproducible light image: a pixel's records by slot
+    `id + s * total_pixels`) against the same records summed per pixel in float32, in exactly that order, in numpy -- byte for
+    byte -- and against the bitonic network's order to the tolerance a re-ordered float sum needs."""
+    scene = c2.create_scene_from_preset("empty", 40, 24)
+    outs = []
+    for stable in (False, True):
+        o = oracle_mod.OracleRenderer(scene)
+        o.make_light_rays(); o.make_camera_rays(); o.trace_light_rays(); o.trace_camera_rays()
+        o.join_paths(); o.finalize_samples()
+        if stable:
+            B = o.batch_size
+            pix = o.out_light_indices.copy()
+            rays = o.out_light_paths["rays"]
+            expect = np.zeros((B, 3), np.float32)
+            wsum = np.zeros(B, np.float32)
+            for slot in np.flatnonzero((pix >= 0) & (pix < B)):          # ascending slot = (s, source pixel)
+                p, ri = o.out_light_path_indices[slot], o.out_light_ray_indices[slot]
+                prior = rays[p, max(ri - 1, 0)]["color"][:3]
+                mat = o.materials["color"][rays[p, ri]["material"]][:3]
+                expect[pix[slot]] += ((o.out_light_weights[slot] * o.out_light_shade[slot]) * prior) * mat
+                wsum[pix[slot]] += o.out_light_weights[slot]
+            fin_w = o.sample_weights.copy()
+        o.gather_light_image(stable=stable)
+        if stable:
+            assert o.out_light_image[:, :3].tobytes() == expect.tobytes()
+            assert o.sample_weights.tobytes() == (fin_w + wsum).tobytes()
+        outs.append(o.out_light_image[:, :3].copy())
+    np.testing.assert_allclose(outs[1], outs[0], rtol=2e-5, atol=1e-9)
+    assert (outs[0] > 0).any()
+
+
 def test_zero_length_paths_are_defined(oracle_mod):
     """a camera path of length 0 contributes nothing and gets zero filter weights."""
     scene = c2.create_scene_from_preset("empty", 16, 16)

@@ -1,5 +1,5 @@
 """Turn the rocprofv3 output of tools/profile_round.sh (gpurun_out/pf_<scene>_*) into the files committed under
-profiles/:   python tools/profile_summaries.py r02 cornell [width height]
+profiles/:   python tools/profile_summaries.py r02 cornell [width height [suffix]]
 
 Writes profiles/<tag>_kernel_stats_<scene>.csv, profiles/<tag>_bench_<scene>.log and profiles/<tag>_pmc_<scene>.json.
 The JSON holds, per kernel and per launch: FETCH_SIZE / WRITE_SIZE (KiB as reported, separate passes), the HBM
@@ -41,16 +41,17 @@ def per_launch(pattern):
 def main():
     tag, scene = sys.argv[1], sys.argv[2]
     W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1920, 1080)
+    suffix = sys.argv[5] if len(sys.argv) > 5 else ""
     import bench
     base = f"gpurun_out/pf_{scene}"
     streams = int(open(f"{base}_streams.txt").read()) if os.path.exists(f"{base}_streams.txt") else 1
     stats = glob.glob(f"{base}_stats/**/*_kernel_stats.csv", recursive=True)
     if stats:
-        shutil.copy(stats[0], f"profiles/{tag}_kernel_stats_{scene}.csv")
+        shutil.copy(stats[0], f"profiles/{tag}_kernel_stats_{scene}{suffix}.csv")
     if os.path.exists(f"{base}_bench.log"):
-        shutil.copy(f"{base}_bench.log", f"profiles/{tag}_bench_{scene}.log")
+        shutil.copy(f"{base}_bench.log", f"profiles/{tag}_bench_{scene}{suffix}.log")
     kernels = collections.defaultdict(dict)
-    for kind in ("fetch", "write", "sq", "tcc"):
+    for kind in ("fetch", "write", "sq", "tcc", "tcp", "ea", "lvl"):
         for k, cs in per_launch(f"{base}_{kind}/**/*_counter_collection.csv").items():
             if "rocclr" in k or "export" in k:
                 continue
@@ -65,6 +66,11 @@ def main():
         if row.get("SQ_WAVE_CYCLES"):
             row["wait_share"] = round(row.get("SQ_WAIT_ANY", 0.0) / row["SQ_WAVE_CYCLES"], 4)
         # average active lanes per VALU wave-instruction: thread-cycles / (4 cycles per quad-cycle-counted instruction)
+        # round 5: average latency of an L1 -> L2 read request (cycles) and of a vector memory read as the wave sees it
+        if row.get("TCP_TCC_READ_REQ_sum") and row.get("TCP_TCC_READ_REQ_LATENCY_sum"):
+            row["l1_miss_latency_cycles"] = round(row["TCP_TCC_READ_REQ_LATENCY_sum"] / row["TCP_TCC_READ_REQ_sum"], 1)
+        if row.get("SQ_INST_LEVEL_VMEM") and row.get("SQ_INSTS_VMEM_RD"):
+            row["vmem_read_latency_cycles"] = round(row["SQ_INST_LEVEL_VMEM"] / row["SQ_INSTS_VMEM_RD"], 1)
         if row.get("SQ_THREAD_CYCLES_VALU") and row.get("SQ_INSTS_VALU"):
             row["thread_cycles_per_valu_inst"] = round(row["SQ_THREAD_CYCLES_VALU"] / row["SQ_INSTS_VALU"], 2)
     # the connection-ray traversal launch: the 4-wide walk where the scene uses it (its left-over launch of the binary
@@ -73,15 +79,15 @@ def main():
             [k for k in kernels if k.startswith("k_traverse_persistent<false") and "ConnRaySource" in k] or
             [k for k in kernels if k.startswith("k_traverse_conn<false")])
     out = {"note": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*, TCC_* each in its own run, --kernel-trace only) of "
-                   f"`python3 bench.py --scene {scene} --no-cpu-baseline --no-mesh --sample-streams {streams} --steps 4 --warmup 1`; values are averages per launch "
+                   f"`python3 bench.py --scene {scene} --no-cpu-baseline --no-mesh --sample-streams {streams} --width {W} --height {H} --steps 4 --warmup 1`; values are averages per launch "
                    f"(a launch of a handle with {streams} sample stream(s) carries the rays of {streams} sample(s)); "
                    "FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count, "
                    "MI355X_MICROARCH.md HBM section); SQ_WAVE_CYCLES/SQ_WAIT_*/SQ_ACTIVE_INST_* are quad-cycles",
            "scene": scene, "width": W, "height": H, "sample_streams": streams, "sources_sha": bench.kernel_sources_sha(),
            "conn_traversal_kernel": conn[0] if conn else None, "kernels": kernels}
-    json.dump(out, open(f"profiles/{tag}_pmc_{scene}.json", "w"), indent=1, sort_keys=True)
+    json.dump(out, open(f"profiles/{tag}_pmc_{scene}{suffix}.json", "w"), indent=1, sort_keys=True)
     if stats:
-        for r in csv.DictReader(open(f"profiles/{tag}_kernel_stats_{scene}.csv")):
+        for r in csv.DictReader(open(f"profiles/{tag}_kernel_stats_{scene}{suffix}.csv")):
             if float(r["Percentage"]) > 1:
                 print(f'{r["Name"][:70]:70s} calls={r["Calls"]:>5s} avg_us={float(r["AverageNs"]) / 1e3:10.1f} pct={r["Percentage"]}')
     for k, row in sorted(kernels.items(), key=lambda kv: -kv[1].get("hbm_bytes", 0))[:8]:
