@@ -288,28 +288,6 @@ struct ConnRaySource {          // connection rays: tag {slot, pixel} -> light v
     }
 };
 
-// Round 5: the same rays with their DIRECTION taken from the queue.  k_connect_setup normalises `target - origin` for its culls
-// anyway (trace.metal:684-688); its writing pass stores that direction beside the tag -- one float4 {d.xyz, tag} per ray -- and the
-// refill of the persistent walks reads it instead of gathering the second vertex and normalising again (a dependent gather,
-// a square root and an exact reciprocal per ray, in all-wave code that runs for a handful of lanes).  Same subtraction, same
-// normalize() on the same operands: the ray is bit for bit the one ConnRaySource rebuilds.
-struct ConnDirRaySource {
-    const float4* cdir; const float4* LP0; float2* chit; int B;
-    __device__ __forceinline__ int load(unsigned j, V3& o, V3& d) const {
-        const float4 c = cdir[j];
-        const int tag = __float_as_int(c.w);
-        const int pid = tag & ((1 << TAG_PID_BITS) - 1), slot = (unsigned)tag >> TAG_PID_BITS;
-        const int s = slot % 6 + 1;
-        o = v3(LP0[(size_t)(s - 1) * B + pid]);
-        d = v3(c);
-        return tag;
-    }
-    __device__ __forceinline__ void store(int tag, const Hit& h) const {
-        const int pid = tag & ((1 << TAG_PID_BITS) - 1), slot = (unsigned)tag >> TAG_PID_BITS;
-        chit_store(chit, B, slot, pid, h.tri, h.t);
-    }
-};
-
 // SGPR budget: 256-thread workgroups are admitted per CU up to floor(800 / (ceil(sgprs / 16) * 16 + 16)) -- 8 up to 80
 // SGPRs, 7 from 81 (MI355X_MICROARCH.md, "Residency").  Left alone the compiler takes 81 for the connection-ray
 // instantiation: one workgroup in eight of the persistent grid then never becomes resident beside the others.
@@ -340,7 +318,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(78))) void k_
 // (The ray tally is added BEFORE the walk: `threadIdx.x == 0` after it would keep the thread index alive through the whole loop,
 // in a kernel held to 64 VGPRs -- round 4's builds spilled exactly that register to scratch at entry and reloaded it at exit.)
 // The tallying variant (cl2_set_counting(2), never timed) carries four more counters per lane and takes 6 waves per SIMD.
-template <int TRI_REPS, class Source, bool TALLY = false>
+template <int TRI_REPS, class Source, bool TALLY = false, bool PREFETCH = false>
 __global__ __launch_bounds__(BLOCK, TALLY ? 6 : 8) __attribute__((amdgpu_num_sgpr(80))) void k_traverse_wide(WideView wide, BvhView bvh, const unsigned* __restrict__ count,
                                                         unsigned* __restrict__ work_counter, Source src, Stats* stats, int is_conn) {
     const unsigned n = *count;
@@ -350,7 +328,7 @@ __global__ __launch_bounds__(BLOCK, TALLY ? 6 : 8) __attribute__((amdgpu_num_sgp
         if (TALLY) atomicAdd(&stats->walk[is_conn ? 1 : 0][0], (unsigned long long)n);
     }
     WalkTally tally;
-    traverse_wide_persistent<TRI_REPS, TALLY>(wide, bvh, n, work_counter, src, tally);
+    traverse_wide_persistent<TRI_REPS, TALLY, PREFETCH>(wide, bvh, n, work_counter, src, tally);
     if (TALLY) {
         unsigned v[4] = {tally.visits, tally.tri_records, tally.spills, tally.bin_nodes};
         for (int off = 32; off > 0; off >>= 1)
@@ -930,16 +908,9 @@ __device__ __forceinline__ size_t clamped_pid(bool valid, int pid) { return vali
 // {slot, pixel}.  Tags are ordered wave-by-wave, slot-major inside a wave, so consecutive queue
 // entries are the same (t,s) strategy of neighbouring pixels: the vertex gathers of
 // k_traverse_conn are coalesced and its rays coherent.
-// WRITE_DIR (the persistent walks' queue, ConnDirRaySource): the writing pass emits {direction, tag} (16 B per ray) into `cdir`
-// instead of the 4-byte tag into `ctag`; the direction is recomputed there for the pairs that passed (the kernel waits for memory
-// four fifths of its time: the arithmetic is free, the 12 extra bytes per ray are not -- which is why the LDS-resident scenes,
-// whose walk is bound by vector issue and saves ~2 % of it, keep the tags).
-// (The direction-writing form keeps the light origins alive across its barrier; it runs beside persistent launches, held to four
-// workgroups per CU by its LDS pad (launch_connect), so it may as well have the registers of four waves per SIMD.)
-template <bool WRITE_DIR>
-__global__ __launch_bounds__(BLOCK, WRITE_DIR ? 4 : 6) void k_connect_setup(
+__global__ __launch_bounds__(BLOCK, 6) void k_connect_setup(
         int B, PathBufs lp, PathBufs cp, const MaterialDev* __restrict__ mats, int n_mats, CameraRec cam,
-        int* __restrict__ ctag, float4* __restrict__ cdir, unsigned* __restrict__ ccount, unsigned long long* __restrict__ cmask) {
+        int* __restrict__ ctag, unsigned* __restrict__ ccount, unsigned long long* __restrict__ cmask) {
     __shared__ unsigned s_wave_total[WAVES_PER_BLOCK];
     __shared__ unsigned s_base;
     __shared__ int s_mtype[256];                           // material types (the table has at most 256 entries, cl2_upload_scene)
@@ -1012,32 +983,18 @@ __global__ __launch_bounds__(BLOCK, WRITE_DIR ? 4 : 6) void k_connect_setup(
     unsigned running = s_base;
     for (int w = 0; w < wave; w++) running += s_wave_total[w];
     if (valid) cmask[pid] = mine;
-    // pass 2: write the ray tags {slot, pixel}; k_traverse_conn rebuilds the ray from the two vertices
+    // pass 2: write the ray tags {slot, pixel}; the traversal kernels rebuild the ray from the two vertices.  (Round 5 measured
+    // the alternative -- this pass writing {direction, tag}, 16 B per ray, so that the persistent walks' refill need not gather
+    // the second vertex and normalise again: the walk gained 1.5 %, this kernel took 0.39 instead of 0.21 ms per sample for its
+    // extra 12 B per ray; profiles/r05_direction_queue.patch.)
 #pragma unroll
     for (int t = 1; t <= MAX_VERTS; t++) {
-        V3 target = focal;
-        if (WRITE_DIR && t > 1) {
-            // camera vertex t-1 again (read in pass 1, three vertices ago: served by the caches); fetched when SOME lane has it
-            float4 c0 = make_float4(0, 0, 0, 0);
-            if (__builtin_amdgcn_ballot_w64(t <= Lc) != 0ull) c0 = cp.P0[(t - 1) * vB + lpid];
-            target = v3(c0);
-        }
 #pragma unroll
         for (int s = 1; s <= MAX_VERTS; s++) {
             const int slot = conn_slot(t, s);
             const bool pred = (mine >> slot) & 1ull;
             const unsigned long long m = __ballot(pred);
-            if (pred) {
-                const unsigned at = running + __popcll(m & ((1ull << lane) - 1ull));
-                const int tag = (slot << TAG_PID_BITS) | pid;
-                if (WRITE_DIR) {
-                    // the direction conn_ray() tested in pass 1 (trace.metal:580 / :684), and the one ConnRaySource would rebuild
-                    const V3 dir = normalize(target - lv[s - 1].o);
-                    cdir[at] = f4(dir, __int_as_float(tag));
-                } else {
-                    ctag[at] = tag;
-                }
-            }
+            if (pred) ctag[running + __popcll(m & ((1ull << lane) - 1ull))] = (slot << TAG_PID_BITS) | pid;
             running += __popcll(m);
         }
     }

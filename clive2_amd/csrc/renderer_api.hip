@@ -100,7 +100,6 @@ struct cl2_renderer {
     int* d_queue = nullptr;            // [6][B], shared by both subpath kinds (they run one after the other)
     unsigned* d_qcount = nullptr;      // [9]: [0] = B (level-0 count), [1..6] level counts, [7] connection rays, [8] = 2B
     int* d_ctag = nullptr;             // connection-ray queue: {slot, pixel} tags
-    float4* d_cdir = nullptr;          // connection-ray queue of the persistent walks: {direction, tag} (ConnDirRaySource); allocated on first use
     // reproducible light image (cl2_set_reproducible, det_splat.hpp): records of one pass, allocated on first use
     bool reproducible = false;
     unsigned long long *d_det_keys = nullptr, *d_det_sorted = nullptr;
@@ -366,14 +365,18 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
     w.n_lds_nodes = std::min(r->n_wide, wflag == 15 ? 0 : (wflag ? 32 * wflag : (streams_from_memory ? 64 : 32)));
     // never more than the 64 KB a workgroup may ask for: the window gives way, the stack entries are needed
     w.n_lds_nodes = std::min<int>(w.n_lds_nodes, (int)(((size_t)64 * 1024 - (size_t)w.stack_lds * BLOCK * 8) / 128));
+    // experiment (debug bits 13 / 14: subpath / connection launches): next-line prefetch of the lanes that test triangles; its
+    // 1 KB sink comes out of the window so that eight workgroups still fit a CU
+    const bool prefetch = r->counting != 2 && ((r->debug_flags >> (13 + stage)) & 1);
+    if (prefetch) w.n_lds_nodes = std::max(0, w.n_lds_nodes - 8);
     const size_t lds = (size_t)w.stack_lds * BLOCK * 8 + (size_t)w.n_lds_nodes * 128;
     // the binary records (lanes whose ray has a non-finite 1/d) come through the caches: no window for them
     BvhView b = r->bvh;
     b.n_lds_nodes = 0; b.lds_tris = 0; b.n_fast_nodes = 0;
-#define CL2_WIDE(REPS, TALLY) \
-    hipLaunchKernelGGL((k_traverse_wide<REPS, Source, TALLY>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
-    if (streams_from_memory) { if (r->counting == 2) CL2_WIDE(1, true); else CL2_WIDE(1, false); }
-    else { if (r->counting == 2) CL2_WIDE(WIDE_TRI_REPS, true); else CL2_WIDE(WIDE_TRI_REPS, false); }
+#define CL2_WIDE(REPS, TALLY, PF) \
+    hipLaunchKernelGGL((k_traverse_wide<REPS, Source, TALLY, PF>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
+    if (streams_from_memory) { if (r->counting == 2) CL2_WIDE(1, true, false); else if (prefetch) CL2_WIDE(1, false, true); else CL2_WIDE(1, false, false); }
+    else { if (r->counting == 2) CL2_WIDE(WIDE_TRI_REPS, true, false); else if (prefetch) CL2_WIDE(WIDE_TRI_REPS, false, true); else CL2_WIDE(WIDE_TRI_REPS, false, false); }
 #undef CL2_WIDE
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;
@@ -496,9 +499,6 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
     const PathBufs& lp = set[CL2_LIGHT];
     const PathBufs& cp = set[CL2_CAMERA];
     HIP_TRY(r, hipMemsetAsync(r->d_qcount + 7, 0, sizeof(unsigned), st));
-    // the persistent walks take their rays' directions from the queue ({direction, tag}, written by the set-up kernel:
-    // ConnDirRaySource); debug bit 13 keeps round 4's form (4-byte tags, the ray rebuilt from its two vertices) for A/B runs
-    const bool dir_queue = split_conn(r) && !((r->debug_flags >> 13) & 1);
     {
         Timed t(r, ST_CONNECT_SETUP, st);
         // Large scenes: this launch (8,100 short workgroups at 7 waves per SIMD) runs beside the persistent subpath launches of
@@ -507,14 +507,8 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
         // -> 10.85 (25 KB: 8.71 / 11.08; 31 KB: 8.44 / 10.98; 52 KB: 8.61 / 10.86).  The Cornell pipeline has no persistent
         // launches and wants the kernel at full speed.
         const size_t pad = split_conn(r) ? (size_t)39 * 1024 : 0;
-        if (dir_queue) {
-            if (!r->d_cdir) TRY(dev_alloc(r, &r->d_cdir, (size_t)CONN_SLOTS * B));
-            hipLaunchKernelGGL(k_connect_setup<true>, dim3(grid_for(B)), dim3(BLOCK), pad, st, B, lp, cp,
-                               r->d_mats, r->n_mats, r->cam, r->d_ctag, r->d_cdir, r->d_qcount + 7, r->d_cmask[cs]);
-        } else {
-            hipLaunchKernelGGL(k_connect_setup<false>, dim3(grid_for(B)), dim3(BLOCK), pad, st, B, lp, cp,
-                               r->d_mats, r->n_mats, r->cam, r->d_ctag, (float4*)nullptr, r->d_qcount + 7, r->d_cmask[cs]);
-        }
+        hipLaunchKernelGGL(k_connect_setup, dim3(grid_for(B)), dim3(BLOCK), pad, st, B, lp, cp,
+                           r->d_mats, r->n_mats, r->cam, r->d_ctag, r->d_qcount + 7, r->d_cmask[cs]);
     }
     HIP_TRY(r, hipGetLastError());
     {
@@ -523,10 +517,8 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
             HIP_TRY(r, hipMemsetAsync(r->d_work + 7 * WORK_STRIDE, 0, WORK_STRIDE * sizeof(unsigned), st));
             ConnRaySource src{r->d_ctag, lp.P0, cp.P0, r->d_chit[cs],
                               V3{r->cam.focal_point[0], r->cam.focal_point[1], r->cam.focal_point[2]}, B};
-            ConnDirRaySource dsrc{r->d_cdir, lp.P0, r->d_chit[cs], B};
             if (wide_walk(r)) {
-                if (dir_queue) TRY(launch_wide(r, st, 1, r->d_qcount + 7, r->d_work + 7 * WORK_STRIDE, dsrc, 1));
-                else TRY(launch_wide(r, st, 1, r->d_qcount + 7, r->d_work + 7 * WORK_STRIDE, src, 1));
+                TRY(launch_wide(r, st, 1, r->d_qcount + 7, r->d_work + 7 * WORK_STRIDE, src, 1));
             } else {
 #define CL2_PERSIST(CNT, TWO, SRCT, SRC)                                                                                  \
             hipLaunchKernelGGL((k_traverse_persistent<CNT, TWO, SRCT>), dim3(persistent_grid_conn(r)), dim3(BLOCK), bvh_lds_bytes(r), \
@@ -536,7 +528,7 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
                 if (two_tris_per_step(r)) { if (count_ref(r)) CL2_PERSIST(true, true, SRCT, SRC); else CL2_PERSIST(false, true, SRCT, SRC); } \
                 else { if (count_ref(r)) CL2_PERSIST(true, false, SRCT, SRC); else CL2_PERSIST(false, false, SRCT, SRC); }      \
             } while (0)
-            if (dir_queue) CL2_PERSIST_SRC(ConnDirRaySource, dsrc); else CL2_PERSIST_SRC(ConnRaySource, src);
+            CL2_PERSIST_SRC(ConnRaySource, src);
 #undef CL2_PERSIST_SRC
 #undef CL2_PERSIST
             }
@@ -665,7 +657,6 @@ void free_pixel_state(cl2_renderer* r) {
             dev_free(r, pb.tri); dev_free(r, pb.len); dev_free(r, pb.carry);
         }
     dev_free(r, r->d_hit); dev_free(r, r->d_hit_cam0); dev_free(r, r->d_queue); dev_free(r, r->d_ctag);
-    dev_free(r, r->d_cdir);
     dev_free(r, r->d_det_keys); dev_free(r, r->d_det_sorted); dev_free(r, r->d_det_vals); dev_free(r, r->d_det_tmp);
     r->det_tmp_bytes = 0;
     for (int q = 0; q < 2; q++) { dev_free(r, r->d_chit[q]); dev_free(r, r->d_cmask[q]); }

@@ -1,5 +1,5 @@
-"""Round 5: the reproducible light image (cl2_set_reproducible), the connection-ray queue that carries directions
-(ConnDirRaySource) and the 4-wide walk's own tallies (cl2_set_counting(2)) -- through the C ABI, against the oracle."""
+"""Round 5: the reproducible light image (cl2_set_reproducible) and the 4-wide walk's own tallies (cl2_set_counting(2)) --
+through the C ABI, against the oracle."""
 import numpy as np
 import pytest
 
@@ -75,27 +75,6 @@ def test_reproducible_light_image_with_sample_streams_and_ragged_frame(oracle_mo
     ai, aw, _, _ = r2.read_accumulators()
     np.testing.assert_allclose(ai, gi, rtol=5e-5, atol=1e-8)
     np.testing.assert_allclose(aw, gw, rtol=5e-5, atol=1e-8)
-
-
-@pytest.mark.parametrize("mode", [2, 5])
-def test_direction_queue_equals_tag_queue(mode, glass_scene, oracle_mod):
-    """The persistent walks' connection-ray queue as {direction, tag} written by k_connect_setup (round 5) and as 4-byte tags
-    with the ray rebuilt from its two vertices (round 4, debug bit 13): same rays, same hits -- aggregators byte for byte equal
-    to each other and to the oracle, same ray count."""
-    out = []
-    for flags in (0, 1 << 13):
-        r, o = _pair(glass_scene, oracle_mod)
-        r.set_traversal_mode(mode)
-        r.set_debug_flags(flags)
-        for x in (r, o):
-            x.make_light_rays(); x.make_camera_rays(); x.trace_light_rays(); x.trace_camera_rays(); x.join_paths()
-        agg = r.export_aggregators()
-        for f in ("weights", "total_contribution", "contrib_weight_sum"):
-            assert agg[f].tobytes() == o.weight_aggregators[f].tobytes(), (flags, f)
-        assert r.counters()["rays"] == o.rays_traced
-        r.run_samples(3)                       # the sample pipeline with rotating buffer sets
-        out.append(r.export_aggregators().tobytes())
-    assert out[0] == out[1]
 
 
 def test_walk_tallies_of_the_wide_walk(glass_scene, oracle_mod):
