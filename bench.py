@@ -160,9 +160,16 @@ def mesh_roofline(row, launch_ms, own_bytes, tree_bytes):
     fetch, write = row.get("FETCH_SIZE"), row.get("WRITE_SIZE")
     if fetch is not None and write is not None:
         raw, x2 = (fetch + write) * 1024.0, (2 * fetch + write) * 1024.0
-        fr["fabric"] = {"achieved": round(x2 / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(x2 / t / 1e9 / HBM_PEAK_GBS, 4),
-                        "raw_gbs": round(raw / t / 1e9, 1), "raw_frac": round(raw / t / 1e9 / HBM_PEAK_GBS, 4), "x2_gbs": round(x2 / t / 1e9, 1),
-                        "bytes_per_launch_raw": round(raw), "bytes_per_launch_x2": round(x2)}
+        # where the request-size mix was profiled (TCC_EA0_RDREQ_{32B,64B,128B}) the read bytes are known exactly and decide;
+        # else the x2 figure does (the larger of the two readings of FETCH_SIZE)
+        sized = row.get("fabric_read_bytes_by_request_size")
+        best = (sized + write * 1024.0) if sized else x2
+        fr["fabric"] = {"achieved": round(best / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(best / t / 1e9 / HBM_PEAK_GBS, 4),
+                        "decided_by": "request-size mix (TCC_EA0_RDREQ_32B / _64B / _128B) + WRITE_SIZE" if sized else "2 x FETCH_SIZE + WRITE_SIZE",
+                        "raw_gbs": round(raw / t / 1e9, 1), "raw_frac": round(raw / t / 1e9 / HBM_PEAK_GBS, 4),
+                        "x2_gbs": round(x2 / t / 1e9, 1), "x2_frac": round(x2 / t / 1e9 / HBM_PEAK_GBS, 4),
+                        "bytes_per_launch_raw": round(raw), "bytes_per_launch_x2": round(x2),
+                        "bytes_per_launch_by_request_size": round(best) if sized else None}
     if not fr:
         return None
     bound = max(fr, key=lambda k: fr[k]["frac"])
@@ -413,6 +420,34 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
                "stages": {k[3:]: round(cb[k] / n_break, 4) for k in cb if k.startswith("ms_")}}
     r.close()
     return out
+
+
+def mesh_leg(args, key, name, W, H, n_steps, streams, local_rank):
+    """One extra workload of the N = 1 line: the timed run with `streams` sample streams, the same with the reference's single
+    seed buffer beside it, the reference's serial loop.  Whatever goes wrong in a leg is reported in its place and never costs
+    the job its headline line."""
+    t_setup = time.perf_counter()
+    leg = {}
+    try:
+        m = run_workload(args, name, W, H, n_steps, 2, 0, local_rank, 1, with_comm=False, streams=streams)
+        leg = dict(m["roofline"], workload=f"{m['scene_desc']} {W}x{H}, {m['steps_rank']} spp in {streams} sample streams",
+                   mrays_per_s=round(m["rays_total"] / m["dt"] / 1e6, 2), ms_per_step=round(m["dt"] / m["steps_rank"] * 1e3, 3),
+                   tuner_samples_in_warmup=m["tuner_samples_in_warmup"], paths_share=m["paths_share"],
+                   stage_ms_per_step_serial=m["stages"])
+        if streams != 1:
+            m1 = run_workload(args, name, W, H, max(8, n_steps // 2), 2, 0, local_rank, 1, with_comm=False, streams=1)
+            leg["one_stream"] = {"sample_streams": 1, "mrays_per_s": round(m1["rays_total"] / m1["dt"] / 1e6, 2),
+                                 "ms_per_step": round(m1["dt"] / m1["steps_rank"] * 1e3, 3), "steps": m1["steps_rank"],
+                                 "bound": m1["roofline"]["bound"], "frac": m1["roofline"]["frac"],
+                                 "frac_launch_alone": m1["roofline"].get("frac_launch_alone"),
+                                 "avg_launch_ms": m1["roofline"]["avg_launch_ms"], "paths_share": m1["paths_share"]}
+        leg["serial_run_sample_ms"] = serial_loop(name, W, H, local_rank)
+    except Exception as exc:                                   # noqa: BLE001
+        print(f"bench.py: leg {key} failed: {exc!r}", file=sys.stderr)
+        leg["error"] = repr(exc)[:300]
+    leg["leg_wall_s"] = round(time.perf_counter() - t_setup, 1)
+    _SCENES.pop((name, W, H, None), None)                      # a 1M-triangle scene is ~0.5 GB of host arrays: one at a time
+    return leg
 
 
 def serial_loop(scene_name, W, H, local_rank, n=8):
@@ -715,7 +750,10 @@ def main():
         if strong_leg:
             out["strong_scaling"] = strong_leg
         if world == 1 and not args.no_mesh:
-            out["serial_run_sample_ms"] = serial_loop(args.scene, W, H, local_rank)
+            try:
+                out["serial_run_sample_ms"] = serial_loop(args.scene, W, H, local_rank)
+            except Exception as exc:                               # noqa: BLE001 -- an extra never costs the job its headline
+                out["serial_run_sample_ms"] = {"error": repr(exc)[:300]}
         if world == 1 and not args.no_mesh and args.scene == "cornell":
             # The other BASELINE.json configurations a single GPU holds, on the same line -- their tree is read through the caches,
             # and each leg says which resource binds its dominant launch (mesh_roofline): config 3 (5,136 triangles), config 4
@@ -729,25 +767,8 @@ def main():
                     ("roofline_hbm", "interior", W, H, args.hbm_steps, K),
                     ("roofline_hbm_4k", "interior", 3840, 2160, args.hbm4k_steps, min(K, args.hbm4k_streams)))
             for key, name, lw, lh, n_steps, k_leg in legs:
-                if n_steps <= 0:
-                    continue
-                t_setup = time.perf_counter()
-                m = run_workload(args, name, lw, lh, n_steps, 2, 0, local_rank, 1, with_comm=False, streams=k_leg)
-                out[key] = dict(m["roofline"], workload=f"{m['scene_desc']} {lw}x{lh}, {m['steps_rank']} spp in {k_leg} sample streams",
-                                mrays_per_s=round(m["rays_total"] / m["dt"] / 1e6, 2),
-                                ms_per_step=round(m["dt"] / m["steps_rank"] * 1e3, 3),
-                                tuner_samples_in_warmup=m["tuner_samples_in_warmup"], paths_share=m["paths_share"],
-                                stage_ms_per_step_serial=m["stages"])
-                if k_leg != 1:
-                    m1 = run_workload(args, name, lw, lh, max(8, n_steps // 2), 2, 0, local_rank, 1, with_comm=False, streams=1)
-                    out[key]["one_stream"] = {"sample_streams": 1, "mrays_per_s": round(m1["rays_total"] / m1["dt"] / 1e6, 2),
-                                              "ms_per_step": round(m1["dt"] / m1["steps_rank"] * 1e3, 3), "steps": m1["steps_rank"],
-                                              "bound": m1["roofline"]["bound"], "frac": m1["roofline"]["frac"],
-                                              "frac_launch_alone": m1["roofline"].get("frac_launch_alone"),
-                                              "avg_launch_ms": m1["roofline"]["avg_launch_ms"], "paths_share": m1["paths_share"]}
-                out[key]["serial_run_sample_ms"] = serial_loop(name, lw, lh, local_rank)
-                out[key]["leg_wall_s"] = round(time.perf_counter() - t_setup, 1)
-                _SCENES.pop((name, lw, lh, None), None)          # a 1M-triangle scene is ~0.5 GB of host arrays: one at a time
+                if n_steps > 0:
+                    out[key] = mesh_leg(args, key, name, lw, lh, n_steps, k_leg, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_width, args.cpu_height, args.cpu_samples)
         sys.stdout.flush()

@@ -93,15 +93,12 @@ constexpr int WIDE_S = WIDE_STACK_LDS;        // stack entries per lane in LDS
 // kernel itself asks of the memory system (bench.py: own bytes = 112 B per wide node + 48 B per triangle record + 48 B per ray).
 struct WalkTally { unsigned visits = 0, tri_records = 0, spills = 0, bin_nodes = 0; };
 
-// PREFETCH (experiment, debug bits 13 / 14): a lane that tests triangles asks for the line it will need NEXT while it tests -- the
-// following pair of its leaf, or what the top of its stack points at (a wide node or a leaf's first triangles) if that entry still
-// passes `tmin < best_t`.  The request is an LDS-direct load (global_load_lds_dword: no destination register, the dword lands in
-// a sink that is never read), issued AFTER the pass's own triangle loads so that their wait does not include it (loads return
-// in order).
-template <int TRI_REPS, bool TALLY, bool PREFETCH, class Source>
+// (Round 5 measured a next-line prefetch here -- a lane that tests triangles asking, by an LDS-direct load into a sink, for the next
+// pair of its leaf or for what the top of its stack points at: subpath launches +7...9 %, connection launch +3 %, on the 5k- and the
+// 1M-triangle scene alike; profiles/r05_prefetch_next_line.patch.  Loads return in order, so the request only moves the wait.)
+template <int TRI_REPS, bool TALLY, class Source>
 __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, const BvhView& b, unsigned n, unsigned* work_counter, const Source& src, WalkTally& tally) {
     constexpr bool TWO_TRIS = true;
-    __shared__ unsigned s_pf_sink[PREFETCH ? WIDE_NT : 1];
     extern __shared__ float4 cl2_tree_lds[];
     const int tid = threadIdx.x;
     constexpr int NT = WIDE_NT;
@@ -299,20 +296,6 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
                 const float4 a0 = ta[0], a1 = ta[1], a2 = ta[2];
                 float4 c0, c1, c2;
                 if (TWO_TRIS) { c0 = tb[0]; c1 = tb[1]; c2 = tb[2]; }
-                if (PREFETCH && rep == TRI_REPS - 1) {
-                    // issued by every lane of the round, unconditionally (a branch around it makes the compiler wait for ALL loads
-                    // at the join, the prefetch included); a lane with nothing to ask for re-requests its own triangle's line
-                    const float4* pf = ta;
-                    if (tri_i < tri_end) pf = w.tris + (size_t)3 * tri_i;                      // the leaf goes on: its next pair
-                    else if (wlane && sp > 0 && sp <= WIDE_S) {
-                        const int2 e = s_stack[(sp - 1) * NT];
-                        const bool live = __int_as_float(e.y) < best.t;
-                        const float4* q = e.x < 0 ? w.tris + (size_t)3 * ((~e.x) >> 4) : w.nodes + (size_t)8 * e.x;
-                        pf = (live && (e.x < 0 || e.x >= n_win)) ? q : pf;
-                    }
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pf,
-                                                     (__attribute__((address_space(3))) void*)(s_pf_sink + (tid & ~63)), 4, 0, 0);
-                }
                 tri_test_branchless(o, d, a0, a1, a2, i0, best);
                 if (TWO_TRIS) tri_test_branchless(o, d, c0, c1, c2, i1, best);
             }

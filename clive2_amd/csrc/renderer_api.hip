@@ -365,18 +365,14 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
     w.n_lds_nodes = std::min(r->n_wide, wflag == 15 ? 0 : (wflag ? 32 * wflag : (streams_from_memory ? 64 : 32)));
     // never more than the 64 KB a workgroup may ask for: the window gives way, the stack entries are needed
     w.n_lds_nodes = std::min<int>(w.n_lds_nodes, (int)(((size_t)64 * 1024 - (size_t)w.stack_lds * BLOCK * 8) / 128));
-    // experiment (debug bits 13 / 14: subpath / connection launches): next-line prefetch of the lanes that test triangles; its
-    // 1 KB sink comes out of the window so that eight workgroups still fit a CU
-    const bool prefetch = r->counting != 2 && ((r->debug_flags >> (13 + stage)) & 1);
-    if (prefetch) w.n_lds_nodes = std::max(0, w.n_lds_nodes - 8);
     const size_t lds = (size_t)w.stack_lds * BLOCK * 8 + (size_t)w.n_lds_nodes * 128;
     // the binary records (lanes whose ray has a non-finite 1/d) come through the caches: no window for them
     BvhView b = r->bvh;
     b.n_lds_nodes = 0; b.lds_tris = 0; b.n_fast_nodes = 0;
-#define CL2_WIDE(REPS, TALLY, PF) \
-    hipLaunchKernelGGL((k_traverse_wide<REPS, Source, TALLY, PF>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
-    if (streams_from_memory) { if (r->counting == 2) CL2_WIDE(1, true, false); else if (prefetch) CL2_WIDE(1, false, true); else CL2_WIDE(1, false, false); }
-    else { if (r->counting == 2) CL2_WIDE(WIDE_TRI_REPS, true, false); else if (prefetch) CL2_WIDE(WIDE_TRI_REPS, false, true); else CL2_WIDE(WIDE_TRI_REPS, false, false); }
+#define CL2_WIDE(REPS, TALLY) \
+    hipLaunchKernelGGL((k_traverse_wide<REPS, Source, TALLY>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
+    if (streams_from_memory) { if (r->counting == 2) CL2_WIDE(1, true); else CL2_WIDE(1, false); }
+    else { if (r->counting == 2) CL2_WIDE(WIDE_TRI_REPS, true); else CL2_WIDE(WIDE_TRI_REPS, false); }
 #undef CL2_WIDE
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;

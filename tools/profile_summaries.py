@@ -51,7 +51,7 @@ def main():
     if os.path.exists(f"{base}_bench.log"):
         shutil.copy(f"{base}_bench.log", f"profiles/{tag}_bench_{scene}{suffix}.log")
     kernels = collections.defaultdict(dict)
-    for kind in ("fetch", "write", "sq", "tcc", "tcp", "ea", "lvl"):
+    for kind in ("fetch", "write", "sq", "tcc", "tcp", "ea", "ea2", "lvl"):
         for k, cs in per_launch(f"{base}_{kind}/**/*_counter_collection.csv").items():
             if "rocclr" in k or "export" in k:
                 continue
@@ -66,6 +66,13 @@ def main():
         if row.get("SQ_WAVE_CYCLES"):
             row["wait_share"] = round(row.get("SQ_WAIT_ANY", 0.0) / row["SQ_WAVE_CYCLES"], 4)
         # average active lanes per VALU wave-instruction: thread-cycles / (4 cycles per quad-cycle-counted instruction)
+        # round 5: the fabric read bytes from the request-size mix (TCC_EA0_RDREQ = 32-byte + 64-byte + 128-byte requests): what
+        # FETCH_SIZE (= RDREQ x 64 B) under- or over-counts for THIS access pattern
+        if all(k in row for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")):
+            n32, n64, n128 = row["TCC_EA0_RDREQ_32B_sum"], row["TCC_EA0_RDREQ_64B_sum"], row["TCC_EA0_RDREQ_128B_sum"]
+            other = row["TCC_EA0_RDREQ_sum"] - n32 - n64 - n128
+            row["fabric_read_bytes_by_request_size"] = round(32 * n32 + 64 * n64 + 128 * n128 + 64 * max(other, 0))
+            row["fabric_read_requests_unsized"] = round(other)
         # round 5: average latency of an L1 -> L2 read request (cycles) and of a vector memory read as the wave sees it
         if row.get("TCP_TCC_READ_REQ_sum") and row.get("TCP_TCC_READ_REQ_LATENCY_sum"):
             row["l1_miss_latency_cycles"] = round(row["TCP_TCC_READ_REQ_LATENCY_sum"] / row["TCP_TCC_READ_REQ_sum"], 1)
