@@ -267,7 +267,7 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
         r.set_debug_flags(args.debug_flags)      # launch-organisation switches only: the library refuses the invalid-render bits
 
     # untimed: the measured launch-organisation choices (bounces per launch of a small scene, stage shares of a large one:
-    # cl2_tune, 1 / 42 real samples), then the counting pass that measures N_node / N_tri per ray
+    # cl2_tune, 1 / 54 real samples), then the counting pass that measures N_node / N_tri per ray
     tuned = r.tune()
     n_count = max(1, -(-max(warmup, 1) // streams))
     r.set_counting(True)

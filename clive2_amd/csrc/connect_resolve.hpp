@@ -60,7 +60,7 @@ __device__ __forceinline__ void resolve_pair(
         unsigned long long mask, float2 h, const float4* __restrict__ tri_shade, const CamTris& cam_tris,
         const MaterialDev* __restrict__ mats, const CameraRec& cam, V3 focal, V3 cam_dir,
         V3& total, float& contrib_weight_sum, float4* __restrict__ light_image, float* splat_tab, int debug_flags,
-        unsigned long long* __restrict__ det_keys, float4* __restrict__ det_vals) {
+        unsigned* __restrict__ det_keys, float4* __restrict__ det_vals) {
     const int tid = threadIdx.x;
     V3 c_o = c_o_in, c_n = c_n_in;
     float c_tot = c_tot_in, c_cos = c_cos_in;
@@ -178,7 +178,7 @@ __device__ __forceinline__ void resolve_pair(
             if (DET) {
                 const size_t rec = (size_t)(S > 0 ? S - 1 : 0) * B + pid;
                 det_vals[rec] = make_float4(c.x, c.y, c.z, w);
-                det_keys[rec] = ((unsigned long long)(unsigned)splat_idx << 32) | (unsigned long long)rec;
+                det_keys[rec] = (unsigned)splat_idx;
                 return;
             }
             // Splat {c.xyz, w} into light_image[pixel] (float4).  The lanes that reach this point
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_connect_resolve(
         const float4* __restrict__ tri_shade, CamTris cam_tris, CameraRec cam, const unsigned long long* __restrict__ cmask,
         const float2* __restrict__ chit, float* __restrict__ agg, float4* __restrict__ light_image,
         float4* __restrict__ uni_out, Stats* stats, int debug_flags,
-        unsigned long long* __restrict__ det_keys, float4* __restrict__ det_vals) {
+        unsigned* __restrict__ det_keys, float4* __restrict__ det_vals) {
     __shared__ float GCs[(MAX_VERTS - 1) * BLOCK];     // GC[v] = G(camera[v], camera[v+1])
     __shared__ float RCs[(MAX_VERTS - 1) * BLOCK];     // RC[m]: ratio of camera vertex m with both neighbours on the camera side
     __shared__ float LNs[3 * MAX_VERTS * BLOCK];       // light vertex normals

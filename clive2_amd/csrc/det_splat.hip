@@ -9,8 +9,9 @@
 
 namespace cl2 {
 
-hipError_t det_sort_keys(void* tmp, size_t& tmp_bytes, const unsigned long long* in, unsigned long long* out, size_t n, hipStream_t st) {
-    return rocprim::radix_sort_keys(tmp, tmp_bytes, in, out, n, 0, 64, st);
+hipError_t det_sort_pairs(void* tmp, size_t& tmp_bytes, const unsigned* keys_in, unsigned* keys_out, const unsigned* slots_in,
+                          unsigned* slots_out, size_t n, unsigned end_bit, hipStream_t st) {
+    return rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, slots_in, slots_out, n, 0u, end_bit, st);
 }
 
 }  // namespace cl2

@@ -1074,28 +1074,30 @@ __global__ __launch_bounds__(BLOCK) void k_finalize(int B, int W, int H, const f
 }
 
 // ---------------------------------------------------------------- reproducible light image (det_splat.hpp)
-// `sorted`: the n record keys of one pass in ascending order = by (target entry, s, source pixel); slots without a
-// contribution hold DET_NO_KEY and sort to the end.  The thread that finds the FIRST key of a target sums that target's run
+// `keys` / `slots`: the n records of one pass sorted stably by target entry, i.e. by (target, s, source pixel); slots without a
+// contribution carry DET_NO_KEY and sort to the end.  The thread that finds the FIRST record of a target sums that target's run
 // front to back and adds it to the light image: one writer per pixel, one order.  Runs are short (<= 6 contributions per source
 // pixel, spread over the film).
-__global__ __launch_bounds__(BLOCK) void k_det_gather(const unsigned long long* __restrict__ sorted, size_t n,
+__global__ __launch_bounds__(BLOCK) void k_det_gather(const unsigned* __restrict__ keys, const unsigned* __restrict__ slots, size_t n,
                                                       const float4* __restrict__ vals, float4* __restrict__ light_image) {
     const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const unsigned long long k = sorted[i];
-    if (k == ~0ull) return;
-    const unsigned pix = (unsigned)(k >> 32);
-    if (i > 0 && (unsigned)(sorted[i - 1] >> 32) == pix) return;
+    const unsigned pix = keys[i];
+    if (pix == ~0u) return;
+    if (i > 0 && keys[i - 1] == pix) return;
     float4 acc = make_float4(0, 0, 0, 0);
-    for (size_t j = i; j < n; j++) {
-        const unsigned long long kj = sorted[j];
-        if ((unsigned)(kj >> 32) != pix) break;                       // the next target, or the first empty slot
-        const float4 v = vals[(unsigned)kj];
+    for (size_t j = i; j < n && keys[j] == pix; j++) {
+        const float4 v = vals[slots[j]];
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     float4 l = light_image[pix];
     l.x += acc.x; l.y += acc.y; l.z += acc.z; l.w += acc.w;
     light_image[pix] = l;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_iota(unsigned* out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[i] = (unsigned)i;
 }
 
 __device__ __forceinline__ float scrub(float x) {   // np.nan_to_num(x, posinf=0, neginf=0)

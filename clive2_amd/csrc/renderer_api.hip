@@ -102,7 +102,7 @@ struct cl2_renderer {
     int* d_ctag = nullptr;             // connection-ray queue: {slot, pixel} tags
     // reproducible light image (cl2_set_reproducible, det_splat.hpp): records of one pass, allocated on first use
     bool reproducible = false;
-    unsigned long long *d_det_keys = nullptr, *d_det_sorted = nullptr;
+    unsigned *d_det_keys = nullptr, *d_det_keys_sorted = nullptr, *d_det_slots = nullptr, *d_det_slots_sorted = nullptr;
     float4* d_det_vals = nullptr;
     void* d_det_tmp = nullptr;
     size_t det_tmp_bytes = 0;
@@ -545,14 +545,24 @@ int launch_connect(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
 }
 
 // buffers of the reproducible light image: one record slot per (light vertex, entry), as the reference's five arrays
+inline unsigned det_key_bits(const cl2_renderer* r) {          // bits of a target entry (< B) plus one for DET_NO_KEY's
+    unsigned bits = 1;
+    while (((size_t)1 << bits) < (size_t)r->B) bits++;
+    return bits + 1;
+}
 int ensure_det_buffers(cl2_renderer* r) {
     if (r->d_det_keys) return CL2_OK;
     const size_t n = (size_t)MAX_VERTS * r->B;
     TRY(dev_alloc(r, &r->d_det_keys, n));
-    TRY(dev_alloc(r, &r->d_det_sorted, n));
+    TRY(dev_alloc(r, &r->d_det_keys_sorted, n));
+    TRY(dev_alloc(r, &r->d_det_slots, n));
+    TRY(dev_alloc(r, &r->d_det_slots_sorted, n));
     TRY(dev_alloc(r, &r->d_det_vals, n));
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(BLOCK), 0, r->stream, r->d_det_slots, n);
+    HIP_TRY(r, hipGetLastError());
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
     size_t bytes = 0;
-    HIP_TRY(r, det_sort_keys(nullptr, bytes, r->d_det_keys, r->d_det_sorted, n, r->stream));
+    HIP_TRY(r, det_sort_pairs(nullptr, bytes, r->d_det_keys, r->d_det_keys_sorted, r->d_det_slots, r->d_det_slots_sorted, n, det_key_bits(r), r->stream));
     unsigned char* tmp = nullptr;
     TRY(dev_alloc(r, &tmp, bytes));
     r->d_det_tmp = tmp; r->det_tmp_bytes = bytes;
@@ -588,7 +598,7 @@ int launch_resolve(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
         if (r->reproducible) {
             // records instead of atomics: every slot starts empty (DET_NO_KEY = all ones)
             TRY(ensure_det_buffers(r));
-            HIP_TRY(r, hipMemsetAsync(r->d_det_keys, 0xFF, (size_t)MAX_VERTS * B * sizeof(unsigned long long), st));
+            HIP_TRY(r, hipMemsetAsync(r->d_det_keys, 0xFF, (size_t)MAX_VERTS * B * sizeof(unsigned), st));
             if (r->n_mats <= LDS_MAT_CAP) CL2_RESOLVE(2, true, true); else CL2_RESOLVE(2, false, true);      // the record stores need registers the 168 of three waves do not leave
         } else {
             // (more than LDS_MAT_CAP materials: the table stays in global memory and its addresses take the registers that three
@@ -599,12 +609,15 @@ int launch_resolve(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
     }
     HIP_TRY(r, hipGetLastError());
     if (r->reproducible) {
-        // order the records by (target entry, s, source pixel), then one thread per target sums its run front to back
+        // a stable sort of {target entry, slot} on the target's bits: a target's run is then ordered by slot = (s, source pixel);
+        // one thread per target sums its run front to back
         Timed t(r, ST_CONNECT_RESOLVE, st);
         const size_t n = (size_t)MAX_VERTS * B;
         size_t bytes = r->det_tmp_bytes;
-        HIP_TRY(r, det_sort_keys(r->d_det_tmp, bytes, r->d_det_keys, r->d_det_sorted, n, st));
-        hipLaunchKernelGGL(k_det_gather, dim3(grid_for(n)), dim3(BLOCK), 0, st, r->d_det_sorted, n, r->d_det_vals, r->d_light_image);
+        HIP_TRY(r, det_sort_pairs(r->d_det_tmp, bytes, r->d_det_keys, r->d_det_keys_sorted, r->d_det_slots, r->d_det_slots_sorted, n,
+                                  det_key_bits(r), st));
+        hipLaunchKernelGGL(k_det_gather, dim3(grid_for(n)), dim3(BLOCK), 0, st, r->d_det_keys_sorted, r->d_det_slots_sorted, n,
+                           r->d_det_vals, r->d_light_image);
         HIP_TRY(r, hipGetLastError());
     }
     return CL2_OK;
@@ -653,7 +666,8 @@ void free_pixel_state(cl2_renderer* r) {
             dev_free(r, pb.tri); dev_free(r, pb.len); dev_free(r, pb.carry);
         }
     dev_free(r, r->d_hit); dev_free(r, r->d_hit_cam0); dev_free(r, r->d_queue); dev_free(r, r->d_ctag);
-    dev_free(r, r->d_det_keys); dev_free(r, r->d_det_sorted); dev_free(r, r->d_det_vals); dev_free(r, r->d_det_tmp);
+    dev_free(r, r->d_det_keys); dev_free(r, r->d_det_keys_sorted); dev_free(r, r->d_det_slots); dev_free(r, r->d_det_slots_sorted);
+    dev_free(r, r->d_det_vals); dev_free(r, r->d_det_tmp);
     r->det_tmp_bytes = 0;
     for (int q = 0; q < 2; q++) { dev_free(r, r->d_chit[q]); dev_free(r, r->d_cmask[q]); }
     dev_free(r, r->d_agg); dev_free(r, r->d_light_image); dev_free(r, r->d_finalized); dev_free(r, r->d_uni);
@@ -714,7 +728,7 @@ int alloc_pixel_state(cl2_renderer* r) {
 
 extern "C" {
 
-int cl2_abi_version(void) { return 3; }
+int cl2_abi_version(void) { return 4; }
 
 int cl2_build_bvh(const double* tri_min, const double* tri_max, int64_t n_triangles, int max_members, int max_depth,
                   void* out_boxes, int64_t box_capacity, int64_t* n_boxes_out, int64_t* out_perm) {
@@ -1317,7 +1331,7 @@ int tune_levels(cl2_renderer* r, int& done) {
 // their wave slots until they run dry, so the stages get fixed shares (persistent_grid_paths/_conn) -- 3, 4
 // or 5 eighths for the subpath stage, no fixed shares, or the serial order.  The best choice depends on the
 // scene and the frame size; every candidate renders TUNE_SAMPLES samples and is timed on the host.
-constexpr int TUNE_TOTAL = 7 * TUNE_SAMPLES;
+constexpr int TUNE_TOTAL = 9 * TUNE_SAMPLES;     // five candidates once, the best two twice more
 inline bool shares_untuned(const cl2_renderer* r) { return pipeline_stages(r) != 0 && split_conn(r) && r->paths_share == 0; }
 int tune_shares(cl2_renderer* r, int& done) {
     if (!shares_untuned(r)) return CL2_OK;
@@ -1332,7 +1346,9 @@ int tune_shares(cl2_renderer* r, int& done) {
         return CL2_OK;
     };
     for (int k = 0; k < 5; k++) TRY(time_one(cand[k], t_of[k]));
-    // the two best once more: neighbouring shares differ by a few per cent, one timing of six samples by about as much
+    // the two best twice more, in turn: neighbouring organisations differ by a few per cent and one timing of six samples by about
+    // as much (round 5: on the 5k-triangle scene with one sample stream the pipelined order, 7.99 ms per sample, lost the run-off
+    // against the serial order, 8.35, in four tunings out of five when each was timed once more)
     int a = 0, b = 1;
     if (t_of[b] < t_of[a]) std::swap(a, b);
     for (int k = 2; k < 5; k++) {
@@ -1340,8 +1356,12 @@ int tune_shares(cl2_renderer* r, int& done) {
         else if (t_of[k] < t_of[b]) b = k;
     }
     double ta = 0, tb = 0;
-    TRY(time_one(cand[a], ta));
-    TRY(time_one(cand[b], tb));
+    for (int round = 0; round < 2; round++) {
+        double t1 = 0, t2 = 0;
+        TRY(time_one(cand[a], t1));
+        TRY(time_one(cand[b], t2));
+        ta += t1; tb += t2;
+    }
     r->paths_share = (t_of[a] + ta <= t_of[b] + tb) ? cand[a] : cand[b];
     return CL2_OK;
 }
@@ -1353,7 +1373,7 @@ int cl2_run_samples(cl2_renderer* r, int n) {
     bool pipe = pipeline_stages(r) != 0 && n > 1;
     int done = 0;
     if (n >= 2) TRY(tune_levels(r, done));
-    // the share tuner runs inside the first LONG call of a scene (its 42 samples are part of the call's n) unless
+    // the share tuner runs inside the first LONG call of a scene (its 54 samples are part of the call's n) unless
     // cl2_tune() ran it before
     if (pipe && n - done >= TUNE_TOTAL + TUNE_SAMPLES + 6) TRY(tune_shares(r, done));
     if (pipe && split_conn(r) && r->paths_share == SHARE_SERIAL) pipe = false;
@@ -1361,7 +1381,7 @@ int cl2_run_samples(cl2_renderer* r, int n) {
 }
 
 /* Makes the measured choices of the launch organisation NOW instead of inside the first (long) cl2_run_samples
- * call: the levels-per-launch probe of a small scene (1 sample) and the stage-share tuner of a large one (42
+ * call: the levels-per-launch probe of a small scene (1 sample) and the stage-share tuner of a large one (54
  * samples: TUNE_TOTAL).  The samples are real ones -- they advance the seeds and add to the accumulators exactly as the same
  * number of run_sample iterations would -- and *samples_rendered says how many there were.  A benchmark calls
  * this in its warm-up so that no timing experiment runs inside its clock. */

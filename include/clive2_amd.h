@@ -132,7 +132,7 @@ int cl2_process_images(cl2_renderer* r);
 int cl2_run_samples(cl2_renderer* r, int n);
 /* Two launch-organisation choices are MEASURED on the scene: bounces per launch for LDS-resident scenes (1 sample)
  * and the share of the machine each pipeline stage gets on large scenes (5 candidates x 6 samples, the best two once more).  By default they
- * are made inside the first cl2_run_samples call that is long enough (>= 2 / >= 54 samples); cl2_tune makes them now.
+ * are made inside the first cl2_run_samples call that is long enough (>= 2 / >= 66 samples); cl2_tune makes them now.
  * Its samples are real ones (seeds advance, accumulators grow, exactly as that many run_sample iterations would);
  * *samples_rendered (may be NULL) says how many.  Benchmarks call it in their warm-up.  No reference counterpart
  * (src/renderer.py:281-291 is one fixed launch sequence). */

@@ -37,6 +37,33 @@ def test_1080p_one_sample_matches_oracle(cornell_1080p, oracle_mod):
     assert uni.tobytes() == o.unidirectional_image_buffer.tobytes()
 
 
+def test_1080p_reproducible_light_image_is_bytewise_the_oracles(cornell_1080p, oracle_mod):
+    """BASELINE config 2 geometry with cl2_set_reproducible (round 5): 1 + 2 samples, all four accumulators byte for byte equal
+    to the oracle's with a pixel's light-image records summed in slot order -- and a second render of the product gives the same
+    bytes (the default path, float atomics, does not: test_1080p_accumulators_are_linear_and_deterministic needs rtol)."""
+    from clive2_amd.renderer import Renderer, make_seeds
+    B = 1920 * 1080
+    seeds = make_seeds(B, rank=5)
+    o = oracle_mod.OracleRenderer(cornell_1080p, seeds=seeds)
+    packed = []
+    for attempt in range(2):
+        r = Renderer(cornell_1080p, seeds=seeds)
+        r.set_reproducible(True)
+        r.run_samples(1)
+        r.run_samples(2)
+        if attempt == 0:
+            for _ in range(3):
+                o.run_sample(stable_light_sort=True)
+            img, wts, cnt, uni = r.read_accumulators()
+            assert img.tobytes() == o.summed_image.tobytes()
+            assert wts.tobytes() == o.summed_sample_weights.tobytes()
+            assert uni.tobytes() == o.unidirectional_image_buffer.tobytes()
+            assert np.array_equal(cnt, o.summed_sample_counts) and (o.summed_image > 0).any()
+        packed.append(r.packed_accumulators().tobytes())
+        r.close()
+    assert packed[0] == packed[1]
+
+
 def test_1080p_accumulators_are_linear_and_deterministic(cornell_1080p):
     from clive2_amd.renderer import Renderer, make_seeds
     seeds = make_seeds(1920 * 1080, rank=3)
@@ -345,15 +372,15 @@ def test_config5_real_size_vs_oracle(interior_real, oracle_mod):
 
 def test_config5_real_size_1080p_and_4k_properties(interior_real):
     """(b) the HIP path at 1920x1080 and at the config's frame, 3840x2160 (8.3 M pixels: 26-bit pixel ids in the
-    connection tags, 36 x 8.3 M result slots), 2 and 1 samples; 56 samples at 1080p let the stage-share tuner run."""
+    connection tags, 36 x 8.3 M result slots), 2 and 1 samples; 68 samples at 1080p let the stage-share tuner run."""
     r, c = _full_frame_properties(interior_real.with_resolution(1920, 1080), 2)
     assert 50 < c["box_tests"] / c["counted_rays"] < 65 and 18 < c["tri_tests"] / c["counted_rays"] < 28
     r.set_counting(False)
-    r.run_samples(56)                                           # >= 54: the share tuner times its candidates (the best two twice)
+    r.run_samples(68)                                           # >= 66: the share tuner times its candidates (the best two three times)
     org = r.organisation()
     assert org["paths_share"] in (3, 4, 5, 8, 9)
     img, wts, cnt, uni = r.read_accumulators()
-    assert (cnt == 58).all() and np.isfinite(img).all()
+    assert (cnt == 70).all() and np.isfinite(img).all()
     r.close()
     r4, c4 = _full_frame_properties(interior_real.with_resolution(3840, 2160), 1)
     assert 50 < c4["box_tests"] / c4["counted_rays"] < 65
@@ -371,9 +398,10 @@ def _same_bytes(a, b):
     return a.size == b.size and bool(np.array_equal(a, b))
 
 
-def _compare_with_oracle(r, o, paths=True):
+def _compare_with_oracle(r, o, paths=True, reproducible=False):
     """Everything one sample leaves behind: RNG state, both Path[] buffers and the filter aggregators bytewise, ray
-    tally, accumulated images (the light-image splat is the one place with a tolerance: float atomics)."""
+    tally, accumulated images (the light-image splat is the one place with a tolerance: float atomics -- and with
+    `reproducible` (cl2_set_reproducible; the oracle summing a pixel's records in slot order) not even that)."""
     assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
     if paths:
         assert _same_bytes(r.export_paths(LIGHT), o.out_light_paths)
@@ -383,8 +411,11 @@ def _compare_with_oracle(r, o, paths=True):
         assert _same_bytes(agg[f], o.weight_aggregators[f]), f
     assert r.counters()["rays"] == o.rays_traced
     img, wts, cnt, uni = r.read_accumulators()
-    np.testing.assert_allclose(img, o.summed_image, rtol=5e-5, atol=1e-8)
-    np.testing.assert_allclose(wts, o.summed_sample_weights, rtol=5e-5, atol=1e-8)
+    if reproducible:
+        assert _same_bytes(img, o.summed_image) and _same_bytes(wts, o.summed_sample_weights)
+    else:
+        np.testing.assert_allclose(img, o.summed_image, rtol=5e-5, atol=1e-8)
+        np.testing.assert_allclose(wts, o.summed_sample_weights, rtol=5e-5, atol=1e-8)
     assert _same_bytes(uni, o.unidirectional_image_buffer)
     assert np.array_equal(cnt, o.summed_sample_counts)
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -393,7 +424,7 @@ def _compare_with_oracle(r, o, paths=True):
     assert l2.max() < 1e-3                                   # the north star's per-pixel bound
 
 
-def _full_frame_vs_oracle(scene, oracle_mod, more=3, forced_shares=(), paths=True):
+def _full_frame_vs_oracle(scene, oracle_mod, more=3, forced_shares=(), paths=True, reproducible=False):
     """One sample through run_samples(1) in the default organisation (serial order), a counting pass for the node /
     triangle tallies, then run_samples(more): the sample pipeline with its rotating buffer sets and stage shares."""
     from clive2_amd.renderer import Renderer, make_seeds
@@ -402,9 +433,10 @@ def _full_frame_vs_oracle(scene, oracle_mod, more=3, forced_shares=(), paths=Tru
     r, o = Renderer(scene, seeds=seeds), oracle_mod.OracleRenderer(scene, seeds=seeds)
     org = r.organisation()
     assert not org["tree_in_lds"] and org["persistent_connections"] and org["wide_connections"]
+    r.set_reproducible(reproducible)
     r.run_samples(1)
-    o.run_sample()
-    _compare_with_oracle(r, o, paths)
+    o.run_sample(stable_light_sort=reproducible)
+    _compare_with_oracle(r, o, paths, reproducible)
     box, tri = int(o.counters["box_tests"][0]), int(o.counters["tri_tests"][0])
     rc = Renderer(scene, seeds=seeds)
     rc.set_counting(True)                                    # the tallies are defined by the binary walk: its own pass
@@ -418,15 +450,15 @@ def _full_frame_vs_oracle(scene, oracle_mod, more=3, forced_shares=(), paths=Tru
         assert r.organisation()["pipeline_stages"] >= 1 or B <= (1 << 19)
         r.run_samples(more)
         for _ in range(more):
-            o.run_sample()
+            o.run_sample(stable_light_sort=reproducible)
         done += more
-        _compare_with_oracle(r, o, paths)
+        _compare_with_oracle(r, o, paths, reproducible)
     for share in forced_shares:                              # the organisations the share tuner chooses between
         r.set_debug_flags(share << 8)
         r.run_samples(2)
-        o.run_sample(); o.run_sample()
+        o.run_sample(stable_light_sort=reproducible); o.run_sample(stable_light_sort=reproducible)
         done += 2
-        _compare_with_oracle(r, o, paths=False)
+        _compare_with_oracle(r, o, paths=False, reproducible=reproducible)
     assert r.samples == done == o.samples
     r.close()
     return c
@@ -437,6 +469,13 @@ def test_config3_1080p_vs_oracle(oracle_mod):
     each with the subpath stage held to 3 and to 5 eighths of the wave slots."""
     c = _full_frame_vs_oracle(_glass(4, 1920, 1080), oracle_mod, more=3, forced_shares=(3, 5))
     assert 8 < c["box_tests"] / c["counted_rays"] < 16       # N_node 11.4 (DESIGN 6)
+
+
+def test_config3_1080p_reproducible_light_image_vs_oracle_bytewise(oracle_mod):
+    """Round 5: the same frame with cl2_set_reproducible -- the light image summed in a fixed order (det_splat.hpp) instead of by
+    float atomics.  No tolerance is left anywhere: summed image and summed weights equal the oracle's (its K8 over the
+    records in slot order) byte for byte, over 1 + 2 samples through the serial order and the sample pipeline."""
+    _full_frame_vs_oracle(_glass(4, 1920, 1080), oracle_mod, more=2, reproducible=True)
 
 
 def test_config4_1080p_vs_oracle(blob_real, oracle_mod):
