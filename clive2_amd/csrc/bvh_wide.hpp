@@ -96,7 +96,16 @@ struct WalkTally { unsigned visits = 0, tri_records = 0, spills = 0, bin_nodes =
 // (Round 5 measured a next-line prefetch here -- a lane that tests triangles asking, by an LDS-direct load into a sink, for the next
 // pair of its leaf or for what the top of its stack points at: subpath launches +7...9 %, connection launch +3 %, on the 5k- and the
 // 1M-triangle scene alike; profiles/r05_prefetch_next_line.patch.  Loads return in order, so the request only moves the wait.)
-template <int TRI_REPS, bool TALLY, class Source>
+// SPEC (round 5; debug bit 13 switches it off for A/B runs and tests): a lane that is busy with a leaf expands the wide node on top
+// of its stack in the same pass -- the node block, which round 4's pass statistics showed running for 32 of 64 lanes, then runs
+// for nearly all of them, and a ray needs fewer passes (same-box A/B, 8 sample streams, ms per sample: 5k triangles 6.64 -> 6.31-6.43,
+// 82k 7.92 -> 7.66, 1M 18.1 -> 17.7-17.9; connection launch alone 2.69 -> 2.55 / 3.23 -> 3.06 / 8.85 -> 8.66;
+// profiles/r05_spec_*.log).  Exact: the entry leaves the stack either
+// way -- pruned now (`tmin >= best_t`, and best_t only shrinks: pruned later too) or replaced by its passing children, ALL of them
+// pushed in the reference's order and each re-tested against best_t when it is popped; a child that passes under today's best_t
+// but not under the one at pop time is dropped there, exactly as the reference, which tests the parent after the leaf, would never
+// have pushed it (a child's tmin is >= its parent's).  Only while the four possible pushes fit the LDS part of the stack.
+template <int TRI_REPS, bool TALLY, bool SPEC, class Source>
 __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, const BvhView& b, unsigned n, unsigned* work_counter, const Source& src, WalkTally& tally) {
     constexpr bool TWO_TRIS = true;
     extern __shared__ float4 cl2_tree_lds[];
@@ -208,20 +217,34 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
         }
 
         pop_loop();                                                         // lanes that finished a leaf in the previous pass
+        bool spec = false;
+        int spec_ref = -1;
+        if (SPEC) {
+            const bool cand = active && wlane && cur < 0 && tri_i < tri_end && sp > 0 && sp + 3 <= WIDE_S;
+            if (cand) {
+                const int2 e = s_stack[(sp - 1) * NT];
+                if (e.x >= 0) {                                             // a wide node on top: it leaves the stack, pruned or expanded
+                    sp--;
+                    spec = __int_as_float(e.y) < best.t;
+                    spec_ref = e.x;
+                }
+            }
+        }
         // ---- one wide node per lane that stands at one: the slab tests of its four boxes in the reference's visit order ----
-        const bool visit = active && wlane && cur >= 0;
+        const bool visit = active && wlane && (cur >= 0 || (SPEC && spec));
 #ifdef CL2_WALK_HISTO
         h_node = visit;
 #endif
         if (__any(visit)) {
             if (visit) {
                 float4 lx, ly, lz, hx, hy, hz, rf;
-                if (n_win > 0 && cur < n_win) {
-                    const float4* nd = s_nodes + 8 * cur;
+                const int vnode = (SPEC && spec) ? spec_ref : cur;
+                if (n_win > 0 && vnode < n_win) {
+                    const float4* nd = s_nodes + 8 * vnode;
                     lx = nd[0]; ly = nd[1]; lz = nd[2]; hx = nd[3]; hy = nd[4]; hz = nd[5]; rf = nd[6];
                     asm volatile("" ::: "memory");                          // keeps this branch's LDS reads apart from the global loads below
                 } else {
-                    const float4* __restrict__ nd = w.nodes + (size_t)8 * cur;
+                    const float4* __restrict__ nd = w.nodes + (size_t)8 * vnode;
                     lx = nd[0]; ly = nd[1]; lz = nd[2]; hx = nd[3]; hy = nd[4]; hz = nd[5]; rf = nd[6];
                 }
                 cur = -1;
@@ -269,7 +292,11 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
                         }
                     }
                 }
-                if (next_ref != WIDE_EMPTY) take(next_ref);
+                if (SPEC && spec) {
+                    // the lane is busy with its leaf: the slot that would pop first waits on the stack like the others
+                    s_stack[sp * NT] = make_int2(next_ref, __float_as_int(next_tmin));
+                    sp += next_ref != WIDE_EMPTY ? 1 : 0;
+                } else if (next_ref != WIDE_EMPTY) take(next_ref);
             }
             pop_loop();                                                     // lanes whose visit left them empty-handed
         }

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(78))) void k_
 // (The ray tally is added BEFORE the walk: `threadIdx.x == 0` after it would keep the thread index alive through the whole loop,
 // in a kernel held to 64 VGPRs -- round 4's builds spilled exactly that register to scratch at entry and reloaded it at exit.)
 // The tallying variant (cl2_set_counting(2), never timed) carries four more counters per lane and takes 6 waves per SIMD.
-template <int TRI_REPS, class Source, bool TALLY = false>
+template <int TRI_REPS, class Source, bool TALLY = false, bool SPEC = false>
 __global__ __launch_bounds__(BLOCK, TALLY ? 6 : 8) __attribute__((amdgpu_num_sgpr(80))) void k_traverse_wide(WideView wide, BvhView bvh, const unsigned* __restrict__ count,
                                                         unsigned* __restrict__ work_counter, Source src, Stats* stats, int is_conn) {
     const unsigned n = *count;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(BLOCK, TALLY ? 6 : 8) __attribute__((amdgpu_num_sgp
         if (TALLY) atomicAdd(&stats->walk[is_conn ? 1 : 0][0], (unsigned long long)n);
     }
     WalkTally tally;
-    traverse_wide_persistent<TRI_REPS, TALLY>(wide, bvh, n, work_counter, src, tally);
+    traverse_wide_persistent<TRI_REPS, TALLY, SPEC>(wide, bvh, n, work_counter, src, tally);
     if (TALLY) {
         unsigned v[4] = {tally.visits, tally.tri_records, tally.spills, tally.bin_nodes};
         for (int off = 32; off > 0; off >>= 1)
@@ -750,14 +750,23 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
         if (state == LANE_TRAV) {
             if (WIDE && wlane) {
                 pop_next();
-                if (cur >= 0) {
+                // round 5 (bvh_wide.hpp, SPEC): a lane that is busy with a leaf expands the wide node on top of its stack in the same
+                // step; the entry leaves the stack pruned or replaced by ALL its passing children
+                bool spec = false;
+                int spec_ref = -1;
+                if (cur < 0 && tri_i < tri_end && sp > 0 && sp + 3 <= S) {
+                    const int2 e = s_stack[(sp - 1) * BLOCK];
+                    if (e.x >= 0) { sp--; spec = __int_as_float(e.y) < best.t; spec_ref = e.x; }
+                }
+                if (cur >= 0 || spec) {
+                    const int vnode = spec ? spec_ref : cur;
                     float4 lx, ly, lz, hx, hy, hz, rf;
-                    if (wide.n_lds_nodes > 0 && cur < wide.n_lds_nodes) {      // the window's lanes read LDS in a branch of their own: no flat loads
-                        const float4* nd = s_wnodes + 8 * cur;
+                    if (wide.n_lds_nodes > 0 && vnode < wide.n_lds_nodes) {    // the window's lanes read LDS in a branch of their own: no flat loads
+                        const float4* nd = s_wnodes + 8 * vnode;
                         lx = nd[0]; ly = nd[1]; lz = nd[2]; hx = nd[3]; hy = nd[4]; hz = nd[5]; rf = nd[6];
                         asm volatile("" ::: "memory");
                     } else {
-                        const float4* __restrict__ nd = wide.nodes + (size_t)8 * cur;
+                        const float4* __restrict__ nd = wide.nodes + (size_t)8 * vnode;
                         lx = nd[0]; ly = nd[1]; lz = nd[2]; hx = nd[3]; hy = nd[4]; hz = nd[5]; rf = nd[6];
                     }
                     cur = -1;
@@ -798,7 +807,11 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
                             }
                         }
                     }
-                    if (next_ref == WIDE_EMPTY) pop_next();
+                    if (spec) {
+                        s_stack[sp * BLOCK] = make_int2(next_ref, __float_as_int(next_tmin));      // sp < S: room for four was required
+                        sp += next_ref != WIDE_EMPTY ? 1 : 0;
+                    }
+                    else if (next_ref == WIDE_EMPTY) pop_next();
                     else if (next_ref >= 0) cur = next_ref;
                     else { const int info = ~next_ref; tri_i = info >> 4; tri_end = tri_i + (info & 15) + 1; }
                 }

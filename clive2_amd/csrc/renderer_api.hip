@@ -369,10 +369,11 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
     // the binary records (lanes whose ray has a non-finite 1/d) come through the caches: no window for them
     BvhView b = r->bvh;
     b.n_lds_nodes = 0; b.lds_tris = 0; b.n_fast_nodes = 0;
-#define CL2_WIDE(REPS, TALLY) \
-    hipLaunchKernelGGL((k_traverse_wide<REPS, Source, TALLY>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
-    if (streams_from_memory) { if (r->counting == 2) CL2_WIDE(1, true); else CL2_WIDE(1, false); }
-    else { if (r->counting == 2) CL2_WIDE(WIDE_TRI_REPS, true); else CL2_WIDE(WIDE_TRI_REPS, false); }
+#define CL2_WIDE(REPS, TALLY, SPEC) \
+    hipLaunchKernelGGL((k_traverse_wide<REPS, Source, TALLY, SPEC>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
+    const bool spec = !((r->debug_flags >> 13) & 1);            // speculative expansion of the stack top (bvh_wide.hpp); bit 13: off
+    if (streams_from_memory) { if (r->counting == 2) { if (spec) CL2_WIDE(1, true, true); else CL2_WIDE(1, true, false); } else if (spec) CL2_WIDE(1, false, true); else CL2_WIDE(1, false, false); }
+    else { if (r->counting == 2) { if (spec) CL2_WIDE(WIDE_TRI_REPS, true, true); else CL2_WIDE(WIDE_TRI_REPS, true, false); } else if (spec) CL2_WIDE(WIDE_TRI_REPS, false, true); else CL2_WIDE(WIDE_TRI_REPS, false, false); }
 #undef CL2_WIDE
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;

@@ -108,3 +108,27 @@ def test_walk_tallies_of_the_wide_walk(glass_scene, oracle_mod):
         == o.weight_aggregators["total_contribution"].tobytes()
     with pytest.raises(Exception):
         r.set_counting(3)
+
+
+@pytest.mark.parametrize("mode", [4, 5])
+def test_speculative_stack_top_expansion_is_a_pure_performance_knob(mode, glass_scene, oracle_mod):
+    """Round 5: a lane of the 4-wide walk that is testing triangles expands the wide node on top of its stack in the same pass
+    (csrc/bvh_wide.hpp).  With and without it (debug bit 13) -- and in the whole-subpath launch, which always has it -- subpaths,
+    RNG state, aggregators and ray count equal the oracle's, over one serial and two pipelined samples."""
+    outs = []
+    for flags in (0, 1 << 13):
+        r, o = _pair(glass_scene, oracle_mod)
+        r.set_traversal_mode(mode)
+        r.set_debug_flags(flags)
+        r.run_samples(1); o.run_sample()
+        assert r.export_paths(LIGHT).tobytes() == o.out_light_paths.tobytes()
+        assert r.export_paths(CAMERA).tobytes() == o.out_camera_paths.tobytes()
+        r.run_samples(2); o.run_sample(); o.run_sample()
+        assert np.array_equal(r.get_random_buffer(), o.rand_buffer)
+        agg = r.export_aggregators()
+        for f in ("weights", "total_contribution", "contrib_weight_sum"):
+            assert agg[f].tobytes() == o.weight_aggregators[f].tobytes(), (flags, f)
+        assert r.counters()["rays"] == o.rays_traced
+        outs.append(r.export_paths(CAMERA).tobytes())
+        r.close()
+    assert outs[0] == outs[1]
