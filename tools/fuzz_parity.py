@@ -69,6 +69,12 @@ def main():
         flags |= int(rng.choice([0, 15, 1, 2, 3])) << 20
         if rng.rand() < 0.3:
             flags |= 8                             # the 4-wide walk for the per-level subpath launches in the serial order too
+        # round 5: the 4-wide walk without its speculative stack-top expansion (bit 13); the reproducible light image (records +
+        # stable sort + ordered gather instead of float atomics: the oracle then sums a pixel's records in slot order, and with one
+        # sample stream image and weights must agree byte for byte)
+        if rng.rand() < 0.3:
+            flags |= 1 << 13
+        repro = bool(rng.rand() < 0.4)
         seeds = [make_seeds(B, seed=k, rank=j) for j in range(K)]
         r = Renderer(scene, seeds=seeds[0] if K == 1 else np.stack(seeds), streams=K)
         os_ = [orc.OracleRenderer(scene, seeds=sd) for sd in seeds]
@@ -79,6 +85,7 @@ def main():
             r.set_subpath_gather(*gather)
         r.set_levels_per_launch(levels)
         r.set_pipelining(stages)
+        r.set_reproducible(repro)
         t0 = time.time()
         ok = True
 
@@ -96,7 +103,7 @@ def main():
         ok &= same_paths()
         r.join_paths(); r.finalize_samples(); r.gather_light_image(); r.process_images()
         for x in os_:
-            x.join_paths(); x.finalize_samples(); x.gather_light_image(); x.process_images()
+            x.join_paths(); x.finalize_samples(); x.gather_light_image(stable=repro); x.process_images()
         for j, oj in enumerate(os_):
             r.set_export_stream(j)
             agg = r.export_aggregators()
@@ -104,12 +111,14 @@ def main():
             ok &= agg["weights"].tobytes() == oj.weight_aggregators["weights"].tobytes()
         r.run_samples(3)
         for x in os_:
-            x.run_sample(); x.run_sample(); x.run_sample()
+            x.run_sample(repro); x.run_sample(repro); x.run_sample(repro)
         ok &= bool(np.array_equal(r.get_random_buffer().reshape(K, B, 2), np.stack([x.rand_buffer for x in os_])))
         ok &= same_paths()                                                    # the last sample's subpaths
         ok &= bool(np.allclose(r.read_accumulators()[3], sum(x.unidirectional_image_buffer for x in os_), rtol=2e-6 if K > 1 else 1e-6, atol=0))
         img = r.read_accumulators()[0]
         ok &= bool(np.allclose(img, sum(x.summed_image for x in os_), rtol=5e-5, atol=1e-8))
+        if repro and K == 1:
+            ok &= img.tobytes() == o.summed_image.tobytes() and r.read_accumulators()[1].tobytes() == o.summed_sample_weights.tobytes()
         ok &= r.counters()["rays"] == sum(x.rays_traced for x in os_)
         # the device tone map against the host path on the same accumulators (a byte may move by one where 255*x/(x+w) sits on an integer)
         with np.errstate(all="ignore"):
@@ -117,7 +126,7 @@ def main():
                 dv, hv = r.tone_mapped(which), getattr(r, which)
                 dd = np.abs(dv.astype(np.int16) - hv.astype(np.int16))
                 ok &= bool(dd.max() <= 1 and int((dd > 0).sum()) <= 2)
-        print(f"scene {k}: {desc} tris={len(scene.triangles)} mode={mode} levels={levels} stages={stages} K={K} flags={flags:#x} "
+        print(f"scene {k}: {desc} tris={len(scene.triangles)} mode={mode} levels={levels} stages={stages} K={K} flags={flags:#x} repro={int(repro)} "
               f"len_c={o.out_camera_paths['length'].mean():.2f} {'OK' if ok else 'MISMATCH'} ({time.time() - t0:.1f}s)", flush=True)
         bad += not ok
         r.close()
