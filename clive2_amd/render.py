@@ -34,6 +34,9 @@ def main(argv=None):
                     help="K independent samples of the frame per pass (Renderer(streams=K): one seed buffer each, as K renderers "
                          "would hold; pays on mesh scenes, where it makes every launch K times larger); the samples are rounded up "
                          "to a multiple of K.  1 = the reference's single renderer; auto = by scene and frame size (Renderer.auto_streams)")
+    ap.add_argument("--reproducible", action="store_true",
+                    help="sum the light image in a fixed order (Renderer.set_reproducible) instead of with float atomics: two runs "
+                         "then write the same bytes, as the reference's sort + gather chain does (renderer.py:212-250); slower")
     args = ap.parse_args(argv)
 
     rank, local_rank, world = rank_info()
@@ -45,6 +48,8 @@ def main(argv=None):
         device = args.device
     renderer = Renderer(scene, device=device, streams=args.sample_streams if args.sample_streams == "auto" else max(1, args.sample_streams))
     K = renderer.streams
+    if args.reproducible:
+        renderer.set_reproducible(True)
     # seed buffers of the job: stream k of rank r is buffer r * K + k
     renderer.set_seeds(stream_seeds(args.width * args.height, K, first_rank=rank * K))
     if world > 1:

@@ -458,6 +458,11 @@ def test_render_cli_writes_an_image(tmp_path):
     from PIL import Image
     img = np.asarray(Image.open(out))
     assert img.shape == (36, 64, 3) and img.std() > 1          # a picture, not a constant
+    # --reproducible: two runs write the same file, byte for byte
+    a, b = tmp_path / "a.png", tmp_path / "b.png"
+    for f in (a, b):
+        assert render.main(["--scene", "empty", "--width", "64", "--height", "36", "--samples", "3", "--reproducible", "--out", str(f)]) == 0
+    assert a.read_bytes() == b.read_bytes()
     with pytest.raises(ValueError):
         render.main(["--scene", "no-such-preset", "--width", "8", "--height", "8", "--samples", "1"])
 
