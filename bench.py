@@ -118,10 +118,13 @@ def static_pmc(scene, W, H, streams=1):
             continue
         if d.get("scene") != scene or d.get("sources_sha") != sha or (d.get("width"), d.get("height")) != (W, H) or d.get("sample_streams", 1) != streams:
             continue
-        row = d.get("kernels", {}).get(d.get("conn_traversal_kernel"))
+        # the timed launch, not the tallying variant of the warm-up's counting pass (k_traverse_wide<REPS, Source, TALLY, SPEC>)
+        wide = [k for k in d.get("kernels", {}) if k.startswith("k_traverse_wide<") and ",ConnRaySource,false" in k]
+        name = wide[0] if wide else d.get("conn_traversal_kernel")
+        row = d.get("kernels", {}).get(name)
         if row:
-            sub = [k for k in d["kernels"] if k.startswith("k_traverse_wide<") and ",PathRaySource" in k]
-            return dict(row, source=os.path.relpath(path, ROOT), sources_sha=d["sources_sha"],
+            sub = [k for k in d["kernels"] if k.startswith("k_traverse_wide<") and ",PathRaySource,false" in k]
+            return dict(row, name=name, source=os.path.relpath(path, ROOT), sources_sha=d["sources_sha"],
                         subpath_kernel=dict(d["kernels"][sub[0]], name=sub[0]) if sub else None)
     return None
 
@@ -179,7 +182,8 @@ def mesh_roofline(row, launch_ms, own_bytes, tree_bytes):
     if own_bytes:
         out["own_bytes"] = dict(own_bytes, gbs=round(own_bytes["bytes_per_launch"] / t / 1e9, 1))
         if "l2" in fr:
-            out["own_bytes"]["passed_on_by_l1"] = round(fr["l2"]["requests_per_launch"] * LINE_BYTES / max(own_bytes["bytes_per_launch"], 1), 3)
+            # (above 1 where lines are used in part: a 48-byte triangle record that straddles two lines costs two requests)
+            out["own_bytes"]["l2_line_bytes_per_own_byte"] = round(fr["l2"]["requests_per_launch"] * LINE_BYTES / max(own_bytes["bytes_per_launch"], 1), 3)
     return out
 
 
@@ -268,7 +272,9 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
 
     # untimed: the measured launch-organisation choices (bounces per launch of a small scene, stage shares of a large one:
     # cl2_tune, 1 / 54 real samples), then the counting pass that measures N_node / N_tri per ray
-    tuned = r.tune()
+    # (CLIVE2_BENCH_SKIP_TUNE=1: the rocprofv3 counter passes of tools/profile_round.sh -- per-launch counters do not depend on how the
+    # stages share the machine, and 54 tuner samples under a serialising profiler take minutes on the 1M-triangle scene)
+    tuned = 0 if os.environ.get("CLIVE2_BENCH_SKIP_TUNE") == "1" else r.tune()
     n_count = max(1, -(-max(warmup, 1) // streams))
     r.set_counting(True)
     r.run_samples(n_count)

@@ -15,7 +15,10 @@
 //   k_traverse_conn / k_traverse_persistent  closest hit for every connection ray
 //   k_connect_resolve (connect_resolve.hpp)  MIS weights + contributions per pixel in the
 //                                            reference's (t,s) order; t=1 splats by float atomics
-//                                            (replaces K4, K7 x300, host bincount, K8)
+//                                            (replaces K4, K7 x300, host bincount, K8) -- or, with
+//                                            cl2_set_reproducible, as the reference's records, sorted
+//                                            stably by target and summed in order by k_det_gather
+//                                            (det_splat.hpp)
 //   k_finalize / k_accumulate                3x3 reconstruction filter, on-device accumulators (K6,
 //                                            renderer.py:253-278)
 //   k_traverse_paths                         closest-hit probe (cl2_probe_traverse)

@@ -57,6 +57,8 @@ struct cl2_renderer {
     hipStream_t stream_conn = nullptr;   // sample pipeline: connection set-up + connection rays
     hipStream_t stream_res = nullptr;    // sample pipeline: resolve + K6 + accumulation
     hipEvent_t ev_paths[3] = {}, ev_conn[2] = {}, ev_res[6] = {};
+    hipEvent_t ev_tune[2] = {};          // share tuner: end of the first / of the last sample of a candidate's run (timing events)
+    double tune_period_ms = 0.0;         // ... and what they measured: ms per sample between the two
     bool pipe_active = false;            // inside a pipelined cl2_run_samples
     int paths_share = 0;                 // eighths of the wave slots given to the subpath stage while pipelining (0 = not tuned yet)
     int pipelining = -1;                 // sample pipeline inside cl2_run_samples: 0 serial, 1 two stages, 2 three stages, -1 by frame size
@@ -786,6 +788,7 @@ int cl2_create(int device_ordinal, int pixel_width, int pixel_height, cl2_render
         for (auto& e : r->ev_paths) ok_ev = ok_ev && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         for (auto& e : r->ev_conn) ok_ev = ok_ev && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         for (auto& e : r->ev_res) ok_ev = ok_ev && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        for (auto& e : r->ev_tune) ok_ev = ok_ev && hipEventCreate(&e) == hipSuccess;
         if (!ok_ev) { r->err = "hipEventCreate failed"; return bail(CL2_E_HIP); }
     }
     int rc = CL2_OK;
@@ -832,6 +835,7 @@ void cl2_destroy(cl2_renderer* r) {
     for (auto e : r->ev_paths) if (e) (void)hipEventDestroy(e);
     for (auto e : r->ev_conn) if (e) (void)hipEventDestroy(e);
     for (auto e : r->ev_res) if (e) (void)hipEventDestroy(e);
+    for (auto e : r->ev_tune) if (e) (void)hipEventDestroy(e);
     for (auto& s : r->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : r->event_pool) (void)hipEventDestroy(e);
     for (void* p : r->allocs) (void)hipFree(p);
@@ -1272,7 +1276,9 @@ int subpath_ray_tally(cl2_renderer* r, unsigned long long* out) {
 
 // `count` samples, serial (one stream, the current buffer set) or pipelined (rotating sets, starting with
 // the current one); ends with everything complete and `cur` = the set of the last sample.
-int run_chunk(cl2_renderer* r, bool pipe, int count) {
+// `steady`: r->tune_period_ms = the time from the end of the first sample to the end of the last one, per sample -- what a long run
+// costs per sample, without the fill of the pipeline (the first sample's subpath stage has nothing beside it).
+int run_chunk(cl2_renderer* r, bool pipe, int count, bool steady = false) {
     const int first_set = r->cur;
     r->pipe_active = pipe;
     for (int i = 0; i < count; i++) {
@@ -1297,6 +1303,7 @@ int run_chunk(cl2_renderer* r, bool pipe, int count) {
         }
         TRY(launch_resolve(r, s_res, set, cs));
         TRY(launch_finalize_accumulate(r, s_res));
+        if (steady && count >= 2 && (i == 0 || i == count - 1)) HIP_TRY(r, hipEventRecord(r->ev_tune[i == 0 ? 0 : 1], s_res));
         if (pipe) HIP_TRY(r, hipEventRecord(r->ev_res[i % 6], s_res));
         r->samples += (uint64_t)r->streams;
         // bound the number of in-flight event pairs while profiling
@@ -1304,6 +1311,11 @@ int run_chunk(cl2_renderer* r, bool pipe, int count) {
     }
     r->pipe_active = false;
     TRY(drain(r));
+    if (steady && count >= 2) {
+        float ms = 0.0f;
+        HIP_TRY(r, hipEventElapsedTime(&ms, r->ev_tune[0], r->ev_tune[1]));
+        r->tune_period_ms = (double)ms / (count - 1);
+    }
     if (pipe && count > 0) r->cur = (first_set + count - 1) % 3;
     return CL2_OK;
 }
@@ -1339,10 +1351,13 @@ int tune_shares(cl2_renderer* r, int& done) {
     const int cand[5] = {3, 4, 5, 8, SHARE_SERIAL};
     double t_of[5];
     auto time_one = [&](int e, double& t) -> int {
+        // Timed on the device from the end of the candidate's first sample to the end of its last: the host clock around six
+        // samples charged a pipelined organisation its fill (about one sample in six) and the serial order nothing -- round 5: with
+        // one sample stream the tuner took the serial order (8.35 / 10.3 ms per sample on the 5k- / 82k-triangle scene) although the
+        // pipelined one runs at 8.0 / 9.9 in a long call.
         r->paths_share = e;
-        const auto t0 = std::chrono::steady_clock::now();
-        TRY(run_chunk(r, e != SHARE_SERIAL, TUNE_SAMPLES));
-        t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        TRY(run_chunk(r, e != SHARE_SERIAL, TUNE_SAMPLES, true));
+        t = r->tune_period_ms;
         done += TUNE_SAMPLES;
         return CL2_OK;
     };

@@ -20,7 +20,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pf_${SCENE}_stats -
 echo "stats pass done"
 pass() {  # name, counters...
     local name=$1; shift
-    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pf_${SCENE}_$name -o runc -- python3 $B --steps $PSTEPS --warmup 1 > $OUT/pf_${SCENE}_$name.log 2>&1
+    CLIVE2_BENCH_SKIP_TUNE=1 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pf_${SCENE}_$name -o runc -- python3 $B --steps $PSTEPS --warmup 1 > $OUT/pf_${SCENE}_$name.log 2>&1
     echo "$name pass done"
 }
 pass fetch FETCH_SIZE

@@ -82,7 +82,8 @@ def main():
             row["thread_cycles_per_valu_inst"] = round(row["SQ_THREAD_CYCLES_VALU"] / row["SQ_INSTS_VALU"], 2)
     # the connection-ray traversal launch: the 4-wide walk where the scene uses it (its left-over launch of the binary
     # kernel carries a handful of rays), else the binary persistent walk, else the LDS kernel of the small scenes
-    conn = ([k for k in kernels if k.startswith("k_traverse_wide<") and "ConnRaySource" in k] or
+    # (k_traverse_wide<REPS, Source, TALLY, SPEC>: the tallying variant runs in the warm-up's counting pass only and is not the launch)
+    conn = ([k for k in kernels if k.startswith("k_traverse_wide<") and "ConnRaySource,false" in k] or
             [k for k in kernels if k.startswith("k_traverse_persistent<false") and "ConnRaySource" in k] or
             [k for k in kernels if k.startswith("k_traverse_conn<false")])
     out = {"note": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*, TCC_* each in its own run, --kernel-trace only) of "
