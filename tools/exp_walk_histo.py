@@ -24,6 +24,9 @@ def show(tag, h):
         print(f"  {names[k]:28s} mean {mean:5.1f}   share of passes with 0 / 1-8 / 9-16 / 17-32 / 33-64 lanes: {q}")
     leaf = h[4][:17]
     print("  triangles per entered leaf:", {i: int(v) for i, v in enumerate(leaf) if v}, "mean %.2f" % ((leaf * np.arange(17)).sum() / max(leaf.sum(), 1)))
+    deep = h[5]
+    print("  deepest stack of a wave's lanes per pass: mean %.2f, share of passes with > 5 entries (no room to speculate): %.1f %%" %
+          ((deep * np.arange(65)).sum() / max(deep.sum(), 1), 100.0 * deep[6:].sum() / max(deep.sum(), 1)))
 
 
 def main():
@@ -31,9 +34,9 @@ def main():
     K = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     r = Renderer(scene, streams=K)
     L = r._L
-    buf = np.zeros((5, 65), np.uint64)
+    buf = np.zeros((6, 65), np.uint64)                        # g_walk_histo[6][65]: the sixth row is the deepest stack per pass
     get = lambda: (L.cl2_walk_histo(r._h, buf.ctypes.data_as(C.c_void_p)), buf.copy())[1]
-    r.set_debug_flags(8)                       # the wide walk for the per-level subpath launches in the serial order too
+    r.set_debug_flags(8 | (int(sys.argv[4], 0) if len(sys.argv) > 4 else 0))      # (+ e.g. 0x2000: without the speculative expansion)
     r.set_traversal_mode(5)
     r.make_light_rays(); r.make_camera_rays()
     get()
