@@ -446,6 +446,8 @@ def mesh_leg(args, key, name, W, H, n_steps, streams, local_rank):
                                  "ms_per_step": round(m1["dt"] / m1["steps_rank"] * 1e3, 3), "steps": m1["steps_rank"],
                                  "bound": m1["roofline"]["bound"], "frac": m1["roofline"]["frac"],
                                  "frac_launch_alone": m1["roofline"].get("frac_launch_alone"),
+                                 "fractions": {k: v["frac"] for k, v in (m1["roofline"].get("fractions") or {}).items()} or None,
+                                 "active_lanes_per_valu_inst": m1["roofline"].get("active_lanes_per_valu_inst"),
                                  "avg_launch_ms": m1["roofline"]["avg_launch_ms"], "paths_share": m1["paths_share"]}
         leg["serial_run_sample_ms"] = serial_loop(name, W, H, local_rank)
     except Exception as exc:                                   # noqa: BLE001

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX from the repo root: the committed profiles of a round for every bench workload --
-#   bash tools/profile_all.sh <tag> [small|interior|interior4k|all]          (e.g. r05)
+#   bash tools/profile_all.sh <tag> [small|interior|interior4k|k1|all]          (e.g. r05)
 # tools/profile_round.sh per workload (rocprofv3 --kernel-trace --stats, then the PMC passes, each in its own run), summarised by
 # tools/profile_summaries.py into gpurun_out/profiles_<tag>/ (copy those into profiles/).
 set -e
@@ -19,5 +19,6 @@ case "${2:-all}" in
   small) run cornell 32 4 1 1920 1080 ""; run glass 32 8 8 1920 1080 ""; run blob 32 8 8 1920 1080 "" ;;
   interior) run interior 24 8 8 1920 1080 "" ;;
   interior4k) run interior 8 2 2 3840 2160 "_4k" ;;
+  k1) run glass 32 4 1 1920 1080 "_k1"; run blob 32 4 1 1920 1080 "_k1"; run interior 16 4 1 1920 1080 "_k1"; run interior 8 2 1 3840 2160 "_4k_k1" ;;   # the legs' one_stream figures
   all) run cornell 32 4 1 1920 1080 ""; run glass 32 8 8 1920 1080 ""; run blob 32 8 8 1920 1080 ""; run interior 24 8 8 1920 1080 ""; run interior 8 2 2 3840 2160 "_4k" ;;
 esac
