@@ -16,6 +16,7 @@ OUT=gpurun_out
 mkdir -p $OUT
 B="bench.py --scene $SCENE --no-cpu-baseline --no-mesh --sample-streams $K --width $W --height $H"
 echo $K > $OUT/pf_${SCENE}_streams.txt
+echo $STEPS > $OUT/pf_${SCENE}_steps.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pf_${SCENE}_stats -o runc -- python3 $B --steps $STEPS --warmup 4 > $OUT/pf_${SCENE}_stats.log 2>&1
 echo "stats pass done"
 pass() {  # name, counters...

@@ -86,18 +86,38 @@ def main():
     conn = ([k for k in kernels if k.startswith("k_traverse_wide<") and "ConnRaySource,false" in k] or
             [k for k in kernels if k.startswith("k_traverse_persistent<false") and "ConnRaySource" in k] or
             [k for k in kernels if k.startswith("k_traverse_conn<false")])
+    # The --stats average of a kernel covers EVERY launch of the process: the share tuner's 54 passes (other grid shares: slower launches),
+    # the timed region, the serial-order breakdown pass.  What bench.py's live `avg_launch_ms` must agree with is the timed region's
+    # launches alone: the last `passes + breakdown passes` launches of the connection kernel in the kernel trace, the breakdown's cut off.
+    timed = None
+    trace = glob.glob(f"{base}_stats/**/*_kernel_trace.csv", recursive=True)
+    if trace and conn and os.path.exists(f"{base}_steps.txt"):
+        steps = int(open(f"{base}_steps.txt").read())
+        passes = max(1, -(-steps // streams))
+        n_break = max(1, min(passes, max(1, 8 // streams)))
+        spans = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(trace[0])) if short(r["Kernel_Name"]) == conn[0])
+        if len(spans) >= passes + n_break:
+            t = spans[-(passes + n_break):-n_break]
+            a = spans[-n_break:]
+            timed = {"kernel": conn[0], "launches_in_timed_region": passes, "avg_ms": round(sum(e - b for b, e in t) / len(t) / 1e6, 4),
+                     "serial_breakdown_launches": n_break, "alone_avg_ms": round(sum(e - b for b, e in a) / len(a) / 1e6, 4),
+                     "all_launches": len(spans), "all_launches_avg_ms": round(sum(e - b for b, e in spans) / len(spans) / 1e6, 4),
+                     "what": "rocprofv3 --kernel-trace of `bench.py --scene ... --steps %d`: the launches of the timed region (pipelined), of the serial "
+                             "breakdown pass (alone) and of the whole process (tuner included: what the --stats average covers)" % steps}
     out = {"note": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*, TCC_* each in its own run, --kernel-trace only) of "
                    f"`python3 bench.py --scene {scene} --no-cpu-baseline --no-mesh --sample-streams {streams} --width {W} --height {H} --steps 4 --warmup 1`; values are averages per launch "
                    f"(a launch of a handle with {streams} sample stream(s) carries the rays of {streams} sample(s)); "
                    "FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count, "
                    "MI355X_MICROARCH.md HBM section); SQ_WAVE_CYCLES/SQ_WAIT_*/SQ_ACTIVE_INST_* are quad-cycles",
            "scene": scene, "width": W, "height": H, "sample_streams": streams, "sources_sha": bench.kernel_sources_sha(),
-           "conn_traversal_kernel": conn[0] if conn else None, "kernels": kernels}
+           "conn_traversal_kernel": conn[0] if conn else None, "kernel_trace_timed_region": timed, "kernels": kernels}
     json.dump(out, open(f"profiles/{tag}_pmc_{scene}{suffix}.json", "w"), indent=1, sort_keys=True)
     if stats:
         for r in csv.DictReader(open(f"profiles/{tag}_kernel_stats_{scene}{suffix}.csv")):
             if float(r["Percentage"]) > 1:
                 print(f'{r["Name"][:70]:70s} calls={r["Calls"]:>5s} avg_us={float(r["AverageNs"]) / 1e3:10.1f} pct={r["Percentage"]}')
+    if timed:
+        print("kernel trace:", timed)
     for k, row in sorted(kernels.items(), key=lambda kv: -kv[1].get("hbm_bytes", 0))[:8]:
         print(f"{k[:60]:60s} hbm {row.get('hbm_bytes', 0) / 1e6:9.1f} MB  VALU {row.get('SQ_INSTS_VALU', 0):.3g}  wait {row.get('wait_share')}  L2 hit {row.get('l2_hit_rate')}")
 
