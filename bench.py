@@ -61,6 +61,116 @@ LINE_BYTES = 128              # one L2 request = one line (tools/l1_gather_rate.
 VALU_PEAK_GINST = 1024 * 2.4e9 / 2.0 / 1e9
 
 
+LINE_CAP = 4000            # characters of the ONE stdout line (the driver keeps 8,000 characters of stdout: BENCH_r05 lost its line to that)
+DETAIL_FILE = "bench_detail.json"
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_leg(leg):
+    """One mesh workload on the stdout line: numbers only, <= 200 characters (the full leg goes to bench_detail.json)."""
+    if not isinstance(leg, dict):
+        return None
+    if "error" in leg and "mrays_per_s" not in leg:
+        return {"error": str(leg["error"])[:80]}
+    one = leg.get("one_stream") or {}
+    ser = leg.get("serial_run_sample_ms") or {}
+    sp = leg.get("subpath_walk") or {}
+    c = {"mrays_per_s": leg.get("mrays_per_s"), "ms_per_step": leg.get("ms_per_step"), "streams": leg.get("sample_streams"),
+         "bound": leg.get("bound"), "frac": leg.get("frac"), "frac_alone": leg.get("frac_launch_alone"),
+         "sub_frac_alone": sp.get("frac_launch_alone"), "pass_fabric": leg.get("pass_fabric_frac"),
+         "k1_mrays_per_s": one.get("mrays_per_s"), "serial_ms": ser.get("ms_per_iteration")}
+    return {k: v for k, v in c.items() if v is not None}
+
+
+def compact_line(out):
+    """The ONE stdout line of the bench contract from the full result: the contract's keys, `roofline` (numbers only) and
+    `cpu_baseline` of the headline workload, and one compact `legs` object for the other workloads.  Everything else -- the four
+    fractions of every leg, own bytes, the contract figure, the subpath walk, prose -- is in bench_detail.json / on stderr.
+    Never longer than LINE_CAP: `legs`, then the optional objects, are dropped before that could happen."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    line["vs_baseline"] = out.get("vs_baseline")
+    line.update(_pick(out, ("dtype", "data")))
+    line["config"] = _pick(out.get("config", {}), ("workload", "width", "height", "rays_per_pixel_sample", "samples_rendered_all_ranks",
+                                                     "sample_streams", "parallelism"))
+    roof = out.get("roofline") or {}
+    r = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "frac_launch_alone", "lane_weighted_frac", "kernel", "rays_per_launch",
+                     "avg_launch_ms", "avg_launch_ms_alone", "wave_insts_per_launch", "active_lanes_per_valu_inst"))
+    r["traffic"] = roof.get("traffic")
+    if isinstance(roof.get("hbm"), dict):
+        r["hbm"] = _pick(roof["hbm"], ("algorithmic_gbs", "bytes_per_ray", "n_node", "n_tri", "measured_gbs", "measured_frac_of_peak"))
+    if isinstance(roof.get("static"), dict):
+        r["static"] = _pick(roof["static"], ("source", "sources_sha"))
+    line["roofline"] = r
+    if isinstance(out.get("stage_ms_per_step_serial"), dict):
+        line["stage_ms"] = {k: round(v, 3) for k, v in out["stage_ms_per_step_serial"].items() if v}
+    if isinstance(out.get("serial_run_sample_ms"), dict) and "ms_per_iteration" in out["serial_run_sample_ms"]:
+        line["serial_ms"] = out["serial_run_sample_ms"]["ms_per_iteration"]
+    names = (("roofline_mesh", "c3_glass_5k"), ("roofline_blob", "c4_blob_82k"), ("roofline_hbm", "c5_interior_1m"),
+             ("roofline_hbm_4k", "c5_interior_1m_4k"))
+    legs = {short: compact_leg(out[key]) for key, short in names if key in out}
+    if legs:
+        line["legs"] = legs
+    if isinstance(out.get("comm"), dict):
+        line["comm"] = _pick(out["comm"], ("nranks", "distinct_devices", "launcher_world_size", "allreduce_ms", "allreduce_bytes", "rank0_device"))
+    if isinstance(out.get("strong_scaling"), dict):
+        ss = out["strong_scaling"]
+        line["strong_scaling"] = dict(_pick(ss, ("scaling", "value", "unit", "seconds", "samples_rendered_all_ranks", "ms_per_sample_whole_job")),
+                                      **({"error": str(ss["error"])[:80]} if "error" in ss else {}))
+    if isinstance(out.get("cpu_baseline"), dict):
+        cb = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "runs"))
+        cb["sample"] = str(out["cpu_baseline"].get("sample", ""))[:160]
+        line["cpu_baseline"] = cb
+    line["detail"] = DETAIL_FILE
+    for obj in (line, line["config"], line["roofline"]):
+        for k, v in obj.items():
+            if isinstance(v, str) and len(v) > 300:
+                obj[k] = v[:300]
+    # the cap is a promise, not a hope: shed the extras (never the contract's keys, `roofline`, `cpu_baseline`) until it holds
+    for victim in ("strong_scaling", "comm", "stage_ms", "legs"):
+        if len(json.dumps(line)) <= LINE_CAP:
+            break
+        if victim == "legs" and "legs" in line:
+            line["legs"] = {k: _pick(v, ("mrays_per_s", "ms_per_step", "frac")) for k, v in line["legs"].items() if v}
+            if len(json.dumps(line)) <= LINE_CAP:
+                break
+        line.pop(victim, None)
+    if len(json.dumps(line)) > LINE_CAP:
+        line["roofline"].pop("static", None)
+        for obj in (line, line["config"], line["roofline"], line.get("cpu_baseline", {})):
+            for k, v in obj.items():
+                if isinstance(v, str) and len(v) > 100:
+                    obj[k] = v[:100]
+    text = json.dumps(line)
+    assert len(text) <= LINE_CAP and "\n" not in text, len(text)
+    return text
+
+
+def emit(out, stdout_fd=None):
+    """Full result -> bench_detail.json beside this script (and under gpurun_out/ when that exists, which travels back from a GPU
+    box); the compact line -> stdout.  stderr gets one short note, not the 20 KB: a driver that keeps a bounded tail of both
+    streams must still find the line (CLIVE2_BENCH_DETAIL_STDERR=1 prints the full result there too)."""
+    full = json.dumps(out)
+    for path in (os.path.join(ROOT, DETAIL_FILE), os.path.join(ROOT, "gpurun_out", DETAIL_FILE)):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    f.write(full + "\n")
+        except OSError as exc:
+            print(f"bench.py: could not write {path}: {exc}", file=sys.stderr)
+    if os.environ.get("CLIVE2_BENCH_DETAIL_STDERR") == "1":
+        print("bench.py detail: " + full, file=sys.stderr, flush=True)
+    else:
+        print(f"bench.py: full result ({len(full)} bytes) in {DETAIL_FILE}", file=sys.stderr, flush=True)
+    text = compact_line(out)
+    sys.stdout.flush()
+    if stdout_fd is not None:
+        os.dup2(stdout_fd, 1)
+    print(text, flush=True)
+
+
 def cpu_baseline(width, height, samples, repeats=2):
     """Oracle (kind 'port'): the CPU restatement of trace.metal's kernels + renderer.py's host glue,
     timed end to end on this host's cores.  Checker code used as the reported baseline only.  The OpenMP team is
@@ -779,9 +889,7 @@ def main():
                     out[key] = mesh_leg(args, key, name, lw, lh, n_steps, k_leg, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_width, args.cpu_height, args.cpu_samples)
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        print(json.dumps(out), flush=True)
+        emit(out, saved_stdout)
     os.close(saved_stdout)
 
 

@@ -554,7 +554,10 @@ inline unsigned det_key_bits(const cl2_renderer* r) {          // bits of a targ
     return bits + 1;
 }
 int ensure_det_buffers(cl2_renderer* r) {
-    if (r->d_det_keys) return CL2_OK;
+    // guarded by the LAST thing set up: a set whose allocation failed half way (CL2_E_NOMEM) is not mistaken for a complete one
+    // by the next sample -- it is freed (dev_free nulls the pointers) and built again
+    if (r->d_det_tmp) return CL2_OK;
+    dev_free(r, r->d_det_keys); dev_free(r, r->d_det_keys_sorted); dev_free(r, r->d_det_slots); dev_free(r, r->d_det_slots_sorted); dev_free(r, r->d_det_vals);
     const size_t n = (size_t)MAX_VERTS * r->B;
     TRY(dev_alloc(r, &r->d_det_keys, n));
     TRY(dev_alloc(r, &r->d_det_keys_sorted, n));
@@ -588,6 +591,8 @@ int launch_resolve(cl2_renderer* r, hipStream_t st, const PathBufs* set, int cs)
         const int occ = (r->debug_flags >> 4) & 7;
         if (occ != 0 && occ != 7) return fail(r, CL2_E_INVALID, "debug bits 4-6 must be 0 or 7");
         if (occ == 7 && r->streams != 1) return fail(r, CL2_E_INVALID, "the cross-check resolve kernel handles one sample stream");
+        // (it splats with atomics and writes no records: the sort + gather below would read buffers it never filled)
+        if (occ == 7 && r->reproducible) return fail(r, CL2_E_INVALID, "the cross-check resolve kernel has no reproducible form: clear debug bits 4-6 or cl2_set_reproducible(0)");
 #ifdef CL2_TEST_VARIANT
         if (occ == 7)
             hipLaunchKernelGGL(k_connect_resolve_wide, dim3((B + RW_PIX - 1) / RW_PIX), dim3(RW_BLOCK), 0, st, B, lp, cp, r->d_mats,

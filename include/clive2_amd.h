@@ -131,7 +131,7 @@ int cl2_gather_light_image(cl2_renderer* r);
 int cl2_process_images(cl2_renderer* r);
 int cl2_run_samples(cl2_renderer* r, int n);
 /* Two launch-organisation choices are MEASURED on the scene: bounces per launch for LDS-resident scenes (1 sample)
- * and the share of the machine each pipeline stage gets on large scenes (5 candidates x 6 samples, the best two once more).  By default they
+ * and the share of the machine each pipeline stage gets on large scenes (9 candidates x 6 samples, the best two twice more in turn: 54 samples, every candidate timed from device events).  By default they
  * are made inside the first cl2_run_samples call that is long enough (>= 2 / >= 66 samples); cl2_tune makes them now.
  * Its samples are real ones (seeds advance, accumulators grow, exactly as that many run_sample iterations would);
  * *samples_rendered (may be NULL) says how many.  Benchmarks call it in their warm-up.  No reference counterpart
@@ -284,7 +284,7 @@ int cl2_read_walk_tallies(cl2_renderer* r, cl2_walk_tallies* out);
  *               closest_hit_flat)
  *   bit 12      invert the one/two-triangles-per-step choice of the persistent walk
  *   bit 13      4-wide walk WITHOUT the speculative expansion of the stack top (round 5: a lane that is testing triangles expands
- *               the wide node on top of its stack in the same pass, csrc/bvh_wide.hpp); round 4's pass
+ *               the wide node on top of its stack in the same pass, csrc/bvh_wide.hpp): the pass as round 4 had it, for A/B runs and tests
  *   bits 16-19  accepted and ignored (round 3: stack entries per lane in LDS of the 4-wide walk; a compile-time 8 since round 4)
  *   bits 20-23  4-wide walk: LDS window of the top of the wide tree in units of 32 nodes (0 = by tree size: 32 nodes, 64 when
  *               the tree streams from memory; 15 = no window)
@@ -298,7 +298,10 @@ int cl2_set_debug_flags(cl2_renderer* r, int flags);
  * src/renderer.py:97-111, :213-250, src/trace.metal:872-964) is deterministic; the float atomics that replace it add a pixel's
  * contributions in hardware order, so two renders agree to a few ulp only.  on = 1: k_connect_resolve writes the reference's
  * records (slot id + s * total_pixels), one radix sort orders them by (target pixel, s, source pixel) and each target's run is
- * summed front to back -- two renders of the same scene and seeds give identical bytes in all four accumulators. */
+ * summed front to back -- two renders of the same scene and seeds give identical bytes in all four accumulators.
+ * Memory: 32 B x 6 x B of records, keys and slot ids (B = sample streams x W x H entries; the sort runs over 6 x B keys) plus
+ * rocPRIM's temporary storage -- 0.4 GB at 1920 x 1080 with one stream, 12.7 GB at 3840 x 2160 with 8.  Refused together with
+ * debug bits 4-6 = 7 (the test variant's cross-check resolve kernel writes no records). */
 int cl2_set_reproducible(cl2_renderer* r, int on);
 int cl2_get_reproducible(const cl2_renderer* r);
 /* Whole-subpath launch (traversal mode 4): lanes that must have gathered with a known closest hit before a wave runs

@@ -56,3 +56,73 @@ def test_committed_pmc_summaries_belong_to_the_kernel_sources_in_the_tree():
         if scene != "cornell":
             assert ",false" in row["name"] and row["subpath_kernel"] and ",false" in row["subpath_kernel"]["name"]      # never the tallying variant
             assert row.get("fabric_read_bytes_by_request_size")
+
+
+def _stored_full_result():
+    return json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+
+
+def test_stdout_line_is_one_short_json_line_with_roofline_and_cpu_baseline():
+    """BENCH_r05.parsed was null: the line had grown to 22.8 KB and the driver keeps 8,000 characters of stdout.  The line is
+    now built by bench.compact_line from the full result (stored here: round 5's own 22.8 KB result) and capped at 4,000."""
+    import bench
+    full = _stored_full_result()
+    assert len(json.dumps(full)) > 20000
+    text = bench.compact_line(full)
+    assert len(text) <= bench.LINE_CAP == 4000 and "\n" not in text
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"] and line["config"]["workload"] == full["config"]["workload"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "rays_per_launch"):
+        assert line["roofline"][k] == full["roofline"][k], k
+    assert line["roofline"]["hbm"]["bytes_per_ray"] == full["roofline"]["hbm"]["bytes_per_ray"]
+    for k in ("value", "unit", "cores", "kind"):
+        assert line["cpu_baseline"][k] == full["cpu_baseline"][k]
+    assert set(line["legs"]) == {"c3_glass_5k", "c4_blob_82k", "c5_interior_1m", "c5_interior_1m_4k"}
+    for leg in line["legs"].values():
+        assert len(json.dumps(leg)) <= 260 and not any(isinstance(v, str) and len(v) > 16 for v in leg.values())      # numbers, no prose
+    assert line["legs"]["c5_interior_1m"]["mrays_per_s"] == full["roofline_hbm"]["mrays_per_s"]
+    assert line["legs"]["c5_interior_1m"]["k1_mrays_per_s"] == full["roofline_hbm"]["one_stream"]["mrays_per_s"]
+
+
+def test_stdout_line_keeps_its_cap_whatever_the_result_grows_to():
+    """The cap is enforced, not hoped for: an N > 1 result with a communicator object of 16 devices, a strong-scaling leg, failed
+    legs with long error texts and a workload string of a kilobyte still gives <= 4,000 characters with `roofline` and
+    `cpu_baseline` intact."""
+    import bench
+    full = _stored_full_result()
+    full["n_gpus"] = 8
+    full["comm"] = {"nranks": 8, "rank0_device": "0000:05:00.0", "devices": ["0000:%02x:00.0" % i for i in range(16)] * 40, "distinct_devices": 8,
+                    "launcher_world_size": 8, "allreduce_ms": 1.234, "allreduce_bytes": 66355200}
+    full["strong_scaling"] = {"workload": "x" * 3000, "scaling": "strong", "value": 1.0, "unit": "Mrays/s", "seconds": 1.0, "comm": full["comm"],
+                              "samples_rendered_all_ranks": 1024, "ms_per_sample_whole_job": 1.0}
+    full["roofline_blob"] = {"error": "RendererError('" + "y" * 5000 + "')", "leg_wall_s": 1.0}
+    full["config"]["workload"] = "z" * 1000
+    full["roofline"]["static"]["what"] = "w" * 5000
+    for i in range(40):
+        full[f"future_key_{i}"] = {"text": "q" * 500}
+    text = bench.compact_line(full)
+    assert len(text) <= 4000
+    line = json.loads(text)
+    assert line["roofline"]["frac"] == full["roofline"]["frac"] and line["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+    assert line["legs"]["c4_blob_82k"]["error"].startswith("RendererError") and len(line["legs"]["c4_blob_82k"]["error"]) <= 80
+    assert line["comm"]["nranks"] == 8 and "devices" not in line["comm"]
+    # pathological: every string field huge -> extras are shed, the contract's keys stay
+    full["config"]["parallelism"] = "p" * 6000
+    line = json.loads(bench.compact_line(full))
+    assert "roofline" in line and "cpu_baseline" in line and "value" in line
+
+
+def test_emit_writes_the_full_result_beside_the_script_and_one_line_to_stdout(tmp_path, monkeypatch, capfd):
+    import bench
+    full = _stored_full_result()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "gpurun_out")
+    bench.emit(full)
+    out, err = capfd.readouterr()
+    assert out.count("\n") == 1 and len(out) <= 4001 and json.loads(out)["detail"] == "bench_detail.json"
+    assert len(err) < 300                                            # a bounded tail of both streams must still hold the line
+    for path in (tmp_path / "bench_detail.json", tmp_path / "gpurun_out" / "bench_detail.json"):
+        assert json.load(open(path)) == full

@@ -815,6 +815,18 @@ def test_wide_resolve_kernel_agrees(scene_name, request, oracle_mod):
     np.testing.assert_allclose(uni, o.unidirectional_image_buffer, rtol=1e-6, atol=0)
     np.testing.assert_allclose(img, o.summed_image, rtol=5e-5, atol=1e-8)
     np.testing.assert_allclose(wts, o.summed_sample_weights, rtol=5e-5, atol=1e-8)
+    # the cross-check kernel splats with atomics and writes no records, so with the reproducible switch on the sort +
+    # gather would read buffers nobody filled (never allocated, on first use).  The combination is refused, the handle stays
+    # usable, and with the bits cleared the reproducible render goes through.
+    r.set_reproducible(True)
+    r.make_light_rays(); r.make_camera_rays(); r.trace_light_rays(); r.trace_camera_rays()
+    with pytest.raises(RendererError, match="reproducible"):
+        r.join_paths()
+    r.set_debug_flags(0)
+    r.join_paths()
+    r.finalize_samples(); r.gather_light_image(); r.process_images()
+    assert np.isfinite(r.read_accumulators()[0]).all()
+    r.close()
 
 
 def test_c_abi_error_behaviour(cornell_small):

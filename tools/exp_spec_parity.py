@@ -1,4 +1,6 @@
-"""Parity of the speculative stack-top expansion (debug bits 13 / 14) against the oracle: small glass scene in modes 0 / 5, the 1080p
+"""Parity of the 4-wide walk WITHOUT the speculative stack-top expansion (debug bit 13 switches it off; the default, flags 0, is the
+speculative walk) against the oracle (round 5's log profiles/r05_spec_parity.log was taken with 0x6000 on the build of
+profiles/r05_spec_pop_between_rounds.patch, whose second-level speculation sat behind bit 14: that bit no longer exists): small glass scene in modes 0 / 5, the 1080p
 config-3 frame (one sample + two pipelined), the 20k-triangle blob at 128x72: Path[] and aggregators byte for byte."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +12,7 @@ from clive2_amd.load import get_materials
 from clive2_amd.meshes import icosphere, noisy_blob
 from oracle import oracle as orc
 orc.build()
-FLAGS = int(sys.argv[1], 0) if len(sys.argv) > 1 else 0x6000
+FLAGS = int(sys.argv[1], 0) if len(sys.argv) > 1 else (1 << 13)
 
 def scene_glass(sub, w, h):
     mats = get_materials(); mats["alpha"][5] = 0.1
