@@ -115,6 +115,8 @@ def compact_line(out):
         line["legs"] = legs
     if isinstance(out.get("comm"), dict):
         line["comm"] = _pick(out["comm"], ("nranks", "distinct_devices", "launcher_world_size", "allreduce_ms", "allreduce_bytes", "rank0_device"))
+        if isinstance(out["comm"].get("devices"), list):
+            line["comm"]["devices"] = [str(d)[:16] for d in out["comm"]["devices"][:16]]      # one PCI address per rank (<= 16 ranks on the line)
     if isinstance(out.get("strong_scaling"), dict):
         ss = out["strong_scaling"]
         line["strong_scaling"] = dict(_pick(ss, ("scaling", "value", "unit", "seconds", "samples_rendered_all_ranks", "ms_per_sample_whole_job")),

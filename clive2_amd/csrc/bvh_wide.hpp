@@ -55,6 +55,7 @@ __device__ unsigned long long g_walk_histo[6][65];
 struct WideView {
     const float4* nodes;       // 8 float4 per wide node
     const float4* tris;        // 3 float4 per triangle (the binary walk's array)
+    const float* tris36;       // PACK: the same records without their padding words, 9 floats {v0, v1 - v0, v2 - v0} per triangle (nullptr: none)
     float4 root_lo, root_hi;   // the root box: tested once per ray, as the reference does
     int2* overflow;            // [lanes of the launch][ovf_stride]
     int ovf_stride;            // entries per lane: the deepest stack the uploaded tree can produce (<= WIDE_STACK_OVERFLOW)
@@ -105,7 +106,11 @@ struct WalkTally { unsigned visits = 0, tri_records = 0, spills = 0, bin_nodes =
 // pushed in the reference's order and each re-tested against best_t when it is popped; a child that passes under today's best_t
 // but not under the one at pop time is dropped there, exactly as the reference, which tests the parent after the leaf, would never
 // have pushed it (a child's tmin is >= its parent's).  Only while the four possible pushes fit the LDS part of the stack.
-template <int TRI_REPS, bool TALLY, bool SPEC, class Source>
+// PACK (round 6; debug bit 14 switches it off): trees that stream from beyond L2 (config 5: the launch moves 0.75 of the HBM peak
+// across the fabric, and most of the lines that miss L2 are TRIANGLE lines) read their triangles as 36-byte records -- a leaf of n
+// triangles is 36 n contiguous bytes instead of 48 n, i.e. fewer 128-byte lines per leaf visit and 12 MB less to keep in the caches
+// per million triangles.  Same values, same operations, same order.
+template <int TRI_REPS, bool TALLY, bool SPEC, bool PACK, class Source>
 __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, const BvhView& b, unsigned n, unsigned* work_counter, const Source& src, WalkTally& tally) {
     constexpr bool TWO_TRIS = true;
     extern __shared__ float4 cl2_tree_lds[];
@@ -318,13 +323,25 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
                 const int i1 = (TWO_TRIS && i0 + 1 < tri_end) ? i0 + 1 : i0;
                 tri_i = i1 + 1;
                 if (TALLY) tally.tri_records += (i1 != i0) ? 2u : 1u;
-                const float4* __restrict__ ta = w.tris + (size_t)3 * i0;
-                const float4* __restrict__ tb = w.tris + (size_t)3 * i1;
-                const float4 a0 = ta[0], a1 = ta[1], a2 = ta[2];
-                float4 c0, c1, c2;
-                if (TWO_TRIS) { c0 = tb[0]; c1 = tb[1]; c2 = tb[2]; }
-                tri_test_branchless(o, d, a0, a1, a2, i0, best);
-                if (TWO_TRIS) tri_test_branchless(o, d, c0, c1, c2, i1, best);
+                if (PACK) {
+                    const float* __restrict__ ta = w.tris36 + (size_t)9 * i0;
+                    const float* __restrict__ tb = w.tris36 + (size_t)9 * i1;
+                    float a[9], c[9];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) a[k] = ta[k];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) c[k] = tb[k];
+                    tri_test_branchless(o, d, make_float4(a[0], a[1], a[2], 0.0f), make_float4(a[3], a[4], a[5], 0.0f), make_float4(a[6], a[7], a[8], 0.0f), i0, best);
+                    tri_test_branchless(o, d, make_float4(c[0], c[1], c[2], 0.0f), make_float4(c[3], c[4], c[5], 0.0f), make_float4(c[6], c[7], c[8], 0.0f), i1, best);
+                } else {
+                    const float4* __restrict__ ta = w.tris + (size_t)3 * i0;
+                    const float4* __restrict__ tb = w.tris + (size_t)3 * i1;
+                    const float4 a0 = ta[0], a1 = ta[1], a2 = ta[2];
+                    float4 c0, c1, c2;
+                    if (TWO_TRIS) { c0 = tb[0]; c1 = tb[1]; c2 = tb[2]; }
+                    tri_test_branchless(o, d, a0, a1, a2, i0, best);
+                    if (TWO_TRIS) tri_test_branchless(o, d, c0, c1, c2, i1, best);
+                }
             }
         }
         // ---- retire: nothing in hand, nothing on the stack ----

@@ -84,6 +84,7 @@ struct cl2_renderer {
     // 4-wide collapse of the tree for the exact wide walk (bvh_wide.hpp); n_wide == 0: not available for this scene
     float4* d_wide = nullptr;
     int n_wide = 0;
+    float* d_tris36 = nullptr;           // 36-byte triangle records of a tree that streams from beyond L2 (bvh_wide.hpp, PACK); nullptr: none
     int n_fast = 0;                      // records of the pruned table (bvh.n_fast_nodes unless debug_flags bit 7 switches it off)
     CamTris cam_tris{0, {0, 0, 0, 0}};   // the triangles with is_camera set, as kernel arguments of the resolve stage (n < 0: too many, look them up)
     int fast_flat = 0;                   // the pruned table is a plain list of leaves (bvh.fast_flat unless debug_flags bit 11 switches it off)
@@ -373,10 +374,15 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
     b.n_lds_nodes = 0; b.lds_tris = 0; b.n_fast_nodes = 0;
 #define CL2_WIDE(REPS, TALLY, SPEC) \
     hipLaunchKernelGGL((k_traverse_wide<REPS, Source, TALLY, SPEC>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
+#define CL2_WIDE_PACK(TALLY, SPEC) \
+    hipLaunchKernelGGL((k_traverse_wide<1, Source, TALLY, SPEC, true>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
     const bool spec = !((r->debug_flags >> 13) & 1);            // speculative expansion of the stack top (bvh_wide.hpp); bit 13: off
-    if (streams_from_memory) { if (r->counting == 2) { if (spec) CL2_WIDE(1, true, true); else CL2_WIDE(1, true, false); } else if (spec) CL2_WIDE(1, false, true); else CL2_WIDE(1, false, false); }
+    const bool pack = streams_from_memory && w.tris36 && !((r->debug_flags >> 14) & 1);      // 36-byte triangle records (bvh_wide.hpp); bit 14: off
+    if (pack) { if (r->counting == 2) { if (spec) CL2_WIDE_PACK(true, true); else CL2_WIDE_PACK(true, false); } else if (spec) CL2_WIDE_PACK(false, true); else CL2_WIDE_PACK(false, false); }
+    else if (streams_from_memory) { if (r->counting == 2) { if (spec) CL2_WIDE(1, true, true); else CL2_WIDE(1, true, false); } else if (spec) CL2_WIDE(1, false, true); else CL2_WIDE(1, false, false); }
     else { if (r->counting == 2) { if (spec) CL2_WIDE(WIDE_TRI_REPS, true, true); else CL2_WIDE(WIDE_TRI_REPS, true, false); } else if (spec) CL2_WIDE(WIDE_TRI_REPS, false, true); else CL2_WIDE(WIDE_TRI_REPS, false, false); }
 #undef CL2_WIDE
+#undef CL2_WIDE_PACK
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;
 }
@@ -1137,8 +1143,23 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     HIP_TRY(r, hipMemcpy(r->d_light_tri_index, light_tri_index, (size_t)light_count * sizeof(int), hipMemcpyHostToDevice));
 
     dev_free(r, r->d_wide);
+    dev_free(r, r->d_tris36);
+    r->wide.tris36 = nullptr;
     r->n_wide = 0;
     if (n_wide > 0) {
+        // a tree that streams from beyond L2 (the size rule of two_tris_per_step_plain): its wide walk reads the triangle records
+        // without their three padding words (36 bytes each; bvh_wide.hpp, PACK)
+        if ((size_t)n_records * 32 + (size_t)n_tris * 48 > ((size_t)16 << 20)) {
+            std::vector<float> h36((size_t)9 * n_tris);
+            for (int t = 0; t < n_tris; t++)
+                for (int v = 0; v < 3; v++) {
+                    const float4 q = h_tris[3 * (size_t)t + v];
+                    h36[9 * (size_t)t + 3 * v] = q.x; h36[9 * (size_t)t + 3 * v + 1] = q.y; h36[9 * (size_t)t + 3 * v + 2] = q.z;
+                }
+            TRY(dev_alloc(r, &r->d_tris36, h36.size()));
+            HIP_TRY(r, hipMemcpy(r->d_tris36, h36.data(), h36.size() * sizeof(float), hipMemcpyHostToDevice));
+            r->wide.tris36 = r->d_tris36;
+        }
         TRY(dev_alloc(r, &r->d_wide, h_wide.size()));
         HIP_TRY(r, hipMemcpy(r->d_wide, h_wide.data(), h_wide.size() * sizeof(float4), hipMemcpyHostToDevice));
         // deepest wide stack of THIS tree (see ensure_wide_overflow); a new scene may need a different size

@@ -108,7 +108,7 @@ def test_stdout_line_keeps_its_cap_whatever_the_result_grows_to():
     line = json.loads(text)
     assert line["roofline"]["frac"] == full["roofline"]["frac"] and line["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
     assert line["legs"]["c4_blob_82k"]["error"].startswith("RendererError") and len(line["legs"]["c4_blob_82k"]["error"]) <= 80
-    assert line["comm"]["nranks"] == 8 and "devices" not in line["comm"]
+    assert line["comm"]["nranks"] == 8 and len(line["comm"]["devices"]) == 16
     # pathological: every string field huge -> extras are shed, the contract's keys stay
     full["config"]["parallelism"] = "p" * 6000
     line = json.loads(bench.compact_line(full))

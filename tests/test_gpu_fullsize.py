@@ -370,6 +370,32 @@ def test_config5_real_size_vs_oracle(interior_real, oracle_mod):
     assert base.export_paths(CAMERA).tobytes() + base.export_paths(LIGHT).tobytes() == ref
 
 
+def test_config5_packed_triangle_records_are_a_pure_performance_knob(interior_real, oracle_mod):
+    """Round 6: the 4-wide walk of a tree that streams from beyond L2 reads 36-byte triangle records ({v0, v1 - v0, v2 - v0}
+    without the padding words; csrc/bvh_wide.hpp PACK).  Default on for this 1M-triangle tree; with debug bit 14 the walk reads
+    the 48-byte records of the other walks.  Both -- per-level wide launches (mode 5) and the automatic organisation, with and
+    without the speculative expansion -- give the oracle's subpaths, aggregators, RNG state and ray count over one serial and
+    two pipelined samples."""
+    from clive2_amd.renderer import Renderer, make_seeds
+    seeds = make_seeds(interior_real.pixel_width * interior_real.pixel_height)
+    o = oracle_mod.OracleRenderer(interior_real, seeds=seeds)
+    for _ in range(3):
+        o.run_sample()
+    for mode, flags in ((5, 0), (5, 1 << 14), (0, 0), (0, 1 << 14), (5, 1 << 13), (5, (1 << 13) | (1 << 14))):
+        r = Renderer(interior_real, seeds=seeds)
+        r.set_traversal_mode(mode); r.set_debug_flags(flags)
+        r.run_samples(1)
+        r.run_samples(2)
+        assert np.array_equal(r.get_random_buffer(), o.rand_buffer), (mode, flags)
+        assert r.export_paths(LIGHT).tobytes() == o.out_light_paths.tobytes(), (mode, flags)
+        assert r.export_paths(CAMERA).tobytes() == o.out_camera_paths.tobytes(), (mode, flags)
+        agg = r.export_aggregators()
+        for f in ("weights", "total_contribution", "contrib_weight_sum"):
+            assert agg[f].tobytes() == o.weight_aggregators[f].tobytes(), (mode, flags, f)
+        assert r.counters()["rays"] == o.rays_traced
+        r.close()
+
+
 def test_config5_real_size_1080p_and_4k_properties(interior_real):
     """(b) the HIP path at 1920x1080 and at the config's frame, 3840x2160 (8.3 M pixels: 26-bit pixel ids in the
     connection tags, 36 x 8.3 M result slots), 2 and 1 samples; 68 samples at 1080p let the stage-share tuner run."""
