@@ -237,8 +237,57 @@ def static_pmc(scene, W, H, streams=1):
         if row:
             sub = [k for k in d["kernels"] if k.startswith("k_traverse_wide<") and ",PathRaySource,false" in k]
             return dict(row, name=name, source=os.path.relpath(path, ROOT), sources_sha=d["sources_sha"],
-                        subpath_kernel=dict(d["kernels"][sub[0]], name=sub[0]) if sub else None)
+                        subpath_kernel=dict(d["kernels"][sub[0]], name=sub[0]) if sub else None, all_kernels=d["kernels"])
     return None
+
+
+def fabric_bytes(row):
+    """Bytes one launch moves across the fabric, from its committed PMC row: reads by request size (TCC_EA0_RDREQ_32B / _64B / _128B)
+    where that pass was taken, else 2 x FETCH_SIZE; plus WRITE_SIZE."""
+    if not row or row.get("WRITE_SIZE") is None:
+        return None
+    reads = row.get("fabric_read_bytes_by_request_size")
+    if reads is None:
+        if row.get("FETCH_SIZE") is None:
+            return None
+        reads = 2 * row["FETCH_SIZE"] * 1024.0
+    return reads + row["WRITE_SIZE"] * 1024.0
+
+
+def pass_fabric(kernels, conn_name, sub_name, sub_launches_per_pass, pass_ms):
+    """What a whole pass (K samples: generators, per-level subpath walks and bounces, connection set-up / walk / resolve, K6) moves
+    across the fabric, against the 8 TB/s HBM peak: sum over kernels of committed fabric bytes per launch x launches per pass,
+    divided by the pass time measured live.  Launches per pass: 1 for the connection walk, the live counter for the per-level
+    subpath walks (their merged level-0 launch, `DualPathRaySource`, is one of them), and for every other kernel its launch count in
+    the PMC run relative to k_connect_setup's (one per pass).  Tallying / counting variants of the walks run in the warm-up only."""
+    if not kernels or pass_ms <= 0:
+        return None
+    setup = kernels.get("k_connect_setup")
+    n_passes = (setup or {}).get("launches_fetch")
+    flags = conn_name.split("ConnRaySource", 1)[1] if conn_name and "ConnRaySource" in conn_name else None      # ",false,true,true>"
+    dual = [k for k in kernels if flags and k.startswith("k_traverse_wide<") and k.endswith("DualPathRaySource" + flags)]
+    total, parts = 0.0, {}
+    for name, row in kernels.items():
+        b = fabric_bytes(row)
+        if b is None:
+            continue
+        if name == conn_name:
+            n = 1.0
+        elif name == sub_name:
+            n = max(sub_launches_per_pass - (1.0 if dual else 0.0), 0.0)
+        elif name in dual:
+            n = 1.0
+        elif name.startswith(("k_traverse_wide<", "k_traverse_persistent<", "k_subpaths_persistent<", "k_traverse_paths", "k_traverse_conn")):
+            continue
+        elif n_passes:
+            n = row.get("launches_fetch", 0) / n_passes
+        else:
+            continue
+        total += b * n
+        parts[name] = round(b * n / 1e9, 2)
+    gbs = total / (pass_ms * 1e-3) / 1e9
+    return {"bytes_per_pass": round(total), "gbs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "peak_gbs": HBM_PEAK_GBS,
+            "pass_ms": round(pass_ms, 3), "gb_per_pass_by_kernel": dict(sorted(parts.items(), key=lambda kv: -kv[1])[:8])}
 
 
 def mesh_roofline(row, launch_ms, own_bytes, tree_bytes):
@@ -525,11 +574,22 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
             sp_ms, sp_rays = c["ms_traverse_paths"] / sp_launches, c["rays_traverse_paths"] / sp_launches
             sp_row = pmc.get("subpath_kernel") if pmc else None
             sp = mesh_roofline(sp_row, sp_ms, own_bytes(own and own["subpath"], sp_rays), tree) or {"bound": None, "frac": None}
+            # the same launches ALONE on the machine (serial breakdown pass): inside the pipeline they share the fabric with the
+            # connection launch, and a fraction taken there says how the fabric is shared, not how far the walk is from its roof
+            sp_alone_ms = cb["ms_traverse_paths"] / max(cb["launches_traverse_paths"], 1)
+            sp_alone = mesh_roofline(sp_row, sp_alone_ms, None, tree)
+            sp["frac_launch_alone"] = sp_alone["frac"] if sp_alone else None
+            sp["fractions_launch_alone"] = {k: v["frac"] for k, v in sp_alone["fractions"].items()} if sp_alone else None
+            sp["avg_launch_ms_alone"] = round(sp_alone_ms, 4)
             sp.update({"kernel": sp_row["name"] if sp_row else "k_traverse_wide<., PathRaySource>", "launches_per_pass": round(sp_launches / max(passes, 1), 2),
                        "avg_launch_ms": round(sp_ms, 4), "rays_per_launch": round(sp_rays),
                        "note": "avg_launch_ms is over ALL subpath traversal launches of the timed region (the merged level-0 launch included); "
                                "the PMC row is the single-kind launch's"})
             roof["subpath_walk"] = sp
+            pf = pass_fabric(pmc.get("all_kernels") if pmc else None, pmc["name"] if pmc else None, sp_row["name"] if sp_row else None,
+                             sp_launches / max(passes, 1), dt / max(passes, 1) * 1e3)
+            roof["pass_fabric"] = pf
+            roof["pass_fabric_frac"] = pf["frac"] if pf else None
         roof.update(common)
         roof["sample_streams"] = streams
         out = {"scene_desc": scene_desc, "rays_total": rays_total, "rays_local": rays_local, "dt": dt, "roofline": roof,

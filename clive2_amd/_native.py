@@ -87,7 +87,7 @@ EXPORTS = [
     "cl2_export_sample_images", "cl2_probe_traverse", "cl2_probe_math", "cl2_probe_bounce",
     "cl2_tune", "cl2_set_subpath_gather", "cl2_comm_abort", "cl2_tone_log_sum", "cl2_tone_map",
     "cl2_set_sample_streams", "cl2_get_sample_streams", "cl2_set_export_stream", "cl2_comm_info",
-    "cl2_read_walk_tallies", "cl2_set_reproducible", "cl2_get_reproducible",
+    "cl2_read_walk_tallies", "cl2_set_reproducible", "cl2_get_reproducible", "cl2_set_traversal_order", "cl2_get_traversal_order",
 ]
 
 
@@ -146,6 +146,8 @@ def lib(variant=None):
         L.cl2_set_subpath_gather.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.cl2_set_sample_streams.argtypes = [C.c_void_p, C.c_int]
         L.cl2_get_sample_streams.argtypes = [C.c_void_p]
+        L.cl2_set_traversal_order.argtypes = [C.c_void_p, C.c_int]
+        L.cl2_get_traversal_order.argtypes = [C.c_void_p]
         L.cl2_set_export_stream.argtypes = [C.c_void_p, C.c_int]
         L.cl2_comm_info.argtypes = [C.c_void_p, C.POINTER(CommInfo)]
         L.cl2_tone_log_sum.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]

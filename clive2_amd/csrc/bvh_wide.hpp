@@ -110,7 +110,14 @@ struct WalkTally { unsigned visits = 0, tri_records = 0, spills = 0, bin_nodes =
 // across the fabric, and most of the lines that miss L2 are TRIANGLE lines) read their triangles as 36-byte records -- a leaf of n
 // triangles is 36 n contiguous bytes instead of 48 n, i.e. fewer 128-byte lines per leaf visit and 12 MB less to keep in the caches
 // per million triangles.  Same values, same operations, same order.
-template <int TRI_REPS, bool TALLY, bool SPEC, bool PACK, class Source>
+// ORDER (round 6; cl2_set_traversal_order(1), never the default and never the parity path): the passing slots of a node are taken
+// NEAREST FIRST (by entry distance, a stable 4-element network on {tmin, ref}; ties keep the reference's slot order) instead of in
+// the reference's fixed order.  A closest-hit query then finds a near hit early and prunes what lies behind it: fewer node visits
+// and triangle tests per ray.  NOT bit-exact by construction: the reference's result depends on its visit order where two
+// triangles are hit at exactly the same t (the first one visited wins, trace.metal:170) and where a hit lies a few ulp in front
+// of its own leaf box's entry distance (the leaf is then pruned or not depending on what was found before it, trace.metal:152).
+// tests/test_gpu_round6.py counts the rays whose hit differs from the exact walk's.
+template <int TRI_REPS, bool TALLY, bool SPEC, bool PACK, bool ORDER, class Source>
 __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, const BvhView& b, unsigned n, unsigned* work_counter, const Source& src, WalkTally& tally) {
     constexpr bool TWO_TRIS = true;
     extern __shared__ float4 cl2_tree_lds[];
@@ -251,12 +258,26 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
                 } else {
                     const float4* __restrict__ nd = w.nodes + (size_t)8 * vnode;
                     lx = nd[0]; ly = nd[1]; lz = nd[2]; hx = nd[3]; hy = nd[4]; hz = nd[5]; rf = nd[6];
+#ifdef CL2_EXTRA_NODE_LOADS
+                    // measurement build only (round 6): N more 16-byte loads of the node's OWN line (its padding words, all zero) -- no new
+                    // line, no new miss, only N more L1 look-ups per visit.  What the launch pays for them is what an L1 look-up costs.
+                    float extra = 0.0f;
+                    int vn[CL2_EXTRA_NODE_LOADS];
+                    float ex[CL2_EXTRA_NODE_LOADS];
+#pragma unroll
+                    for (int e = 0; e < CL2_EXTRA_NODE_LOADS; e++) { vn[e] = vnode; asm("; index copy %1" : "+v"(vn[e]) : "i"(e)); }   // indices the compiler cannot prove equal: PLAIN global loads of their own
+#pragma unroll
+                    for (int e = 0; e < CL2_EXTRA_NODE_LOADS; e++) ex[e] = w.nodes[(size_t)8 * vn[e] + 7].x;
+#pragma unroll
+                    for (int e = 0; e < CL2_EXTRA_NODE_LOADS; e++) extra += ex[e];
+                    lx.x += extra;
+#endif
                 }
                 cur = -1;
                 if (TALLY) tally.visits++;
                 const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
                 const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
-                const int ref[4] = {__float_as_int(rf.x), __float_as_int(rf.y), __float_as_int(rf.z), __float_as_int(rf.w)};
+                int ref[4] = {__float_as_int(rf.x), __float_as_int(rf.y), __float_as_int(rf.z), __float_as_int(rf.w)};
                 float tm[4];
                 bool pass[4];
 #pragma unroll
@@ -268,6 +289,18 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
                     const float tmax = __builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
                     tm[k] = tmin;
                     pass[k] = tmin <= tmax && tmin < best.t;                // an empty slot's box lies at +inf: never
+                }
+                if (ORDER) {
+                    // nearest first: slots that do not pass sort behind all that do (key +inf, no reference); adjacent
+                    // exchanges only, on strict `>`, so equal keys keep the reference's slot order
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { tm[k] = pass[k] ? tm[k] : __builtin_inff(); ref[k] = pass[k] ? ref[k] : WIDE_EMPTY; }
+#define CL2_CSWAP(A, B) { const bool sw = tm[A] > tm[B]; const float ta = tm[A], tb = tm[B]; const int ra = ref[A], rb = ref[B]; \
+                          tm[A] = sw ? tb : ta; tm[B] = sw ? ta : tb; ref[A] = sw ? rb : ra; ref[B] = sw ? ra : rb; }
+                    CL2_CSWAP(0, 1) CL2_CSWAP(1, 2) CL2_CSWAP(2, 3) CL2_CSWAP(0, 1) CL2_CSWAP(1, 2) CL2_CSWAP(0, 1)
+#undef CL2_CSWAP
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pass[k] = ref[k] != WIDE_EMPTY;
                 }
                 // Slots are taken last to first, so that the first one pops first; the candidate found so far is pushed when
                 // another slot passes in front of it, and the one left at the end -- the slot that WOULD pop first -- is what the

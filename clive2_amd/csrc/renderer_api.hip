@@ -67,6 +67,7 @@ struct cl2_renderer {
     int counting = 0;                    // 0 off, 1 the reference walk's node / triangle tallies (binary walk), 2 the 4-wide walk's own tallies
     int profiling = 0;                   // 0 off, 1 the connection-ray traversal launch only, 2 every stage
     int debug_flags = 0;
+    int traversal_order = 0;             // 0 = the reference's child order (exact); 1 = nearest child first in the 4-wide walks (opt-in, NOT bit-exact: bvh_wide.hpp ORDER)
     int gather_lanes = 32, gather_wait = 48;   // whole-subpath launch: lanes gathered / steps waited before a wave runs its bounce phase
     int traversal_mode = 0;              // 0 auto, 1 fused (one ray per lane), 2 split (persistent traversal + ray replacement)
     unsigned* d_work = nullptr;          // [8][WORK_STRIDE] work counters of the persistent traversal launches, a 64-byte line per launch slot
@@ -284,6 +285,7 @@ inline bool wide_walk(const cl2_renderer* r) {
 // lose: there the per-level form wins in serial order too (interior 4K: 53.7 vs 61.6 ms of subpath time, blob 24.0 vs
 // 28.1).  So the automatic choice takes it in the serial order and up to 2^22 pixels only.
 inline bool whole_subpaths(const cl2_renderer* r) {
+    if (r->traversal_order != 0) return false;                       // nearest-first order exists in k_traverse_wide only: every ray goes through it
     if (r->counting == 2 && r->traversal_mode != 4) return false;   // the walk's own tallies are taken in k_traverse_wide: every ray goes through it
     return r->traversal_mode == 4 || (r->traversal_mode == 0 && !tree_in_lds(r) && !r->pipe_active && r->B <= (1 << 22));
 }
@@ -378,6 +380,17 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
     hipLaunchKernelGGL((k_traverse_wide<1, Source, TALLY, SPEC, true>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
     const bool spec = !((r->debug_flags >> 13) & 1);            // speculative expansion of the stack top (bvh_wide.hpp); bit 13: off
     const bool pack = streams_from_memory && w.tris36 && !((r->debug_flags >> 14) & 1);      // 36-byte triangle records (bvh_wide.hpp); bit 14: off
+    if (r->traversal_order != 0) {
+        // opt-in nearest-first child order (cl2_set_traversal_order; NOT the parity path): the speculative walk only
+#define CL2_WIDE_ORDER(REPS, TALLY, PACK) \
+    hipLaunchKernelGGL((k_traverse_wide<REPS, Source, TALLY, true, PACK, true>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
+        if (pack) { if (r->counting == 2) CL2_WIDE_ORDER(1, true, true); else CL2_WIDE_ORDER(1, false, true); }
+        else if (streams_from_memory) { if (r->counting == 2) CL2_WIDE_ORDER(1, true, false); else CL2_WIDE_ORDER(1, false, false); }
+        else { if (r->counting == 2) CL2_WIDE_ORDER(WIDE_TRI_REPS, true, false); else CL2_WIDE_ORDER(WIDE_TRI_REPS, false, false); }
+#undef CL2_WIDE_ORDER
+        HIP_TRY(r, hipGetLastError());
+        return CL2_OK;
+    }
     if (pack) { if (r->counting == 2) { if (spec) CL2_WIDE_PACK(true, true); else CL2_WIDE_PACK(true, false); } else if (spec) CL2_WIDE_PACK(false, true); else CL2_WIDE_PACK(false, false); }
     else if (streams_from_memory) { if (r->counting == 2) { if (spec) CL2_WIDE(1, true, true); else CL2_WIDE(1, true, false); } else if (spec) CL2_WIDE(1, false, true); else CL2_WIDE(1, false, false); }
     else { if (r->counting == 2) { if (spec) CL2_WIDE(WIDE_TRI_REPS, true, true); else CL2_WIDE(WIDE_TRI_REPS, true, false); } else if (spec) CL2_WIDE(WIDE_TRI_REPS, false, true); else CL2_WIDE(WIDE_TRI_REPS, false, false); }
@@ -742,7 +755,7 @@ int alloc_pixel_state(cl2_renderer* r) {
 
 extern "C" {
 
-int cl2_abi_version(void) { return 4; }
+int cl2_abi_version(void) { return 5; }
 
 int cl2_build_bvh(const double* tri_min, const double* tri_max, int64_t n_triangles, int max_members, int max_depth,
                   void* out_boxes, int64_t box_capacity, int64_t* n_boxes_out, int64_t* out_perm) {
@@ -1836,6 +1849,20 @@ int cl2_query_organisation(cl2_renderer* r, cl2_organisation* out) {
     out->sample_streams = r->streams;
     return CL2_OK;
 }
+/* Child order of the 4-wide walks (round 6).  0 (default) = the reference's fixed order (trace.metal:157-160): bit-exact.  1 = the
+ * passing children of a node nearest first: fewer node visits and triangle tests per ray, NOT bit-exact by construction (exact-t ties
+ * between two triangles, hits a few ulp in front of their leaf box; csrc/bvh_wide.hpp ORDER).  Opt-in; applies to scenes whose tree is
+ * read through the caches (an LDS-resident tree such as the Cornell box has no 4-wide walk and renders the same either way); whole-
+ * subpath launches give way to per-level ones, and the reference-walk tallies (cl2_set_counting(1)) stay the binary walk's. */
+int cl2_set_traversal_order(cl2_renderer* r, int order) {
+    if (!r) return CL2_E_INVALID;
+    if (order != 0 && order != 1) return fail(r, CL2_E_INVALID, "traversal order must be 0 (reference order, exact) or 1 (nearest child first)");
+    HIP_TRY(r, hipSetDevice(r->device));
+    TRY(drain(r));
+    r->traversal_order = order;
+    return CL2_OK;
+}
+int cl2_get_traversal_order(const cl2_renderer* r) { return r ? r->traversal_order : CL2_E_INVALID; }
 int cl2_set_debug_flags(cl2_renderer* r, int flags) {
     if (!r) return CL2_E_INVALID;
 #ifndef CL2_TEST_VARIANT

@@ -352,6 +352,15 @@ class Renderer:
         refuses bits 0-2 (they skip parts of the resolve stage and exist only in the test variant)."""
         self._check(self._L.cl2_set_debug_flags(self._h, int(flags)), "set_debug_flags")
 
+    def set_traversal_order(self, order=1):
+        """Child order of the 4-wide walks (cl2_set_traversal_order): 0 = the reference's fixed order (trace.metal:157-160; the
+        default, bit-exact), 1 = nearest child first -- fewer node visits and triangle tests per ray, NOT bit-exact by
+        construction (exact-t ties, hits a few ulp in front of their leaf box).  Opt-in; no reference counterpart."""
+        self._check(self._L.cl2_set_traversal_order(self._h, int(order)), "set_traversal_order")
+
+    def traversal_order(self):
+        return int(self._L.cl2_get_traversal_order(self._h))
+
     def set_reproducible(self, on=True):
         """Reproducible light image (cl2_set_reproducible): the t = 1 contributions sorted and summed in a fixed order instead of
         float atomics -- two renders of the same scene and seeds then agree byte for byte, as the reference's sort + gather

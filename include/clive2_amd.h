@@ -306,6 +306,17 @@ int cl2_set_debug_flags(cl2_renderer* r, int flags);
  * debug bits 4-6 = 7 (the test variant's cross-check resolve kernel writes no records). */
 int cl2_set_reproducible(cl2_renderer* r, int on);
 int cl2_get_reproducible(const cl2_renderer* r);
+/* Child order of the 4-wide walks (ABI 5).  order = 0 (default): the reference's fixed order -- a box's second child is popped first,
+ * whatever the ray (src/trace.metal:157-160) -- which is what makes every output byte-comparable with the reference's.  order = 1:
+ * the passing children of a node are taken NEAREST FIRST (by slab entry distance).  A closest-hit query then prunes what lies behind
+ * its first hit: fewer node visits and triangle tests per ray.  NOT the reference's result by construction -- the reference's hit
+ * depends on its visit order where two triangles are hit at exactly the same t (first visited wins, trace.metal:170) and where a hit
+ * lies a few ulp in front of its leaf box's entry distance (trace.metal:152) -- so: opt-in, never the default, never the parity path;
+ * bench.py's headline and every parity test run with 0, and tests/test_gpu_round6.py counts the rays whose hit differs.  Applies to
+ * scenes whose tree is read through the caches (the 4-wide walk; an LDS-resident tree such as the Cornell box renders the same
+ * either way).  No reference counterpart (src/trace.metal:144-176 has one order). */
+int cl2_set_traversal_order(cl2_renderer* r, int order);
+int cl2_get_traversal_order(const cl2_renderer* r);
 /* Whole-subpath launch (traversal mode 4): lanes that must have gathered with a known closest hit before a wave runs
  * its bounce phase, and the steps the first of them waits at most.  0 = default (32 lanes, 48 steps).  Same results. */
 int cl2_set_subpath_gather(cl2_renderer* r, int lanes, int wait_steps);

@@ -126,3 +126,24 @@ def test_emit_writes_the_full_result_beside_the_script_and_one_line_to_stdout(tm
     assert len(err) < 300                                            # a bounded tail of both streams must still hold the line
     for path in (tmp_path / "bench_detail.json", tmp_path / "gpurun_out" / "bench_detail.json"):
         assert json.load(open(path)) == full
+
+
+def test_pass_fabric_sums_committed_bytes_over_the_kernels_of_a_pass():
+    """`pass_fabric` = sum over kernels (committed fabric bytes per launch x launches per pass) / pass time / 8 TB/s.
+    Hand-made PMC rows: connection walk 400 GB, eleven subpath-walk launches of which one is the merged level-0 launch (10 x 20 GB
+    + 1 x 10 GB), a bounce kernel launched 6 times per pass (24 launches over the 4 passes of the PMC run) at 2 GB, set-up 1 GB;
+    the tallying variants of the walks (warm-up only) do not count."""
+    import bench
+    def row(read_gb, write_gb=0.0, launches=4):
+        return {"fabric_read_bytes_by_request_size": read_gb * 1e9, "WRITE_SIZE": write_gb * 1e9 / 1024.0, "FETCH_SIZE": 0.0, "launches_fetch": launches}
+    conn, sub = "k_traverse_wide<1,ConnRaySource,false,true,true>", "k_traverse_wide<1,PathRaySource,false,true,true>"
+    kernels = {conn: row(390.0, 10.0, 2), sub: row(20.0, 0.0, 20), "k_traverse_wide<1,DualPathRaySource,false,true,true>": row(10.0, 0.0, 2),
+               "k_traverse_wide<1,ConnRaySource,true,true,true>": row(999.0, 0.0, 1), "k_traverse_persistent<true,false,ConnRaySource>": row(999.0, 0.0, 1),
+               "k_trace_subpath<false,false,true>": row(1.0, 1.0, 24), "k_connect_setup": row(0.5, 0.5, 4)}
+    pf = bench.pass_fabric(kernels, conn, sub, 11.0, 100.0)
+    want = 400.0 + 10 * 20.0 + 10.0 + 6 * 2.0 + 1.0
+    assert abs(pf["bytes_per_pass"] - want * 1e9) < 1e6
+    assert abs(pf["gbs"] - want / 0.1) < 1.0 and abs(pf["frac"] - want / 0.1 / 8000.0) < 1e-3
+    assert bench.pass_fabric(None, conn, sub, 11.0, 100.0) is None and bench.pass_fabric(kernels, conn, sub, 11.0, 0.0) is None
+    # a row without the request-size pass: 2 x FETCH_SIZE + WRITE_SIZE (the guide's correction)
+    assert bench.fabric_bytes({"FETCH_SIZE": 1000.0, "WRITE_SIZE": 500.0}) == (2 * 1000.0 + 500.0) * 1024.0

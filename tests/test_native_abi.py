@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(native_lib):
     missing = [n for n in names if not hasattr(native_lib, n)]
     assert missing == []
     assert sorted(_native.EXPORTS) == names          # the binding knows exactly the header's surface
-    assert native_lib.cl2_abi_version() == 4
+    assert native_lib.cl2_abi_version() == 5
 
 
 def test_header_cites_the_reference_interface():
