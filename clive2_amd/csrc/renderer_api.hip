@@ -378,6 +378,8 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
     hipLaunchKernelGGL((k_traverse_wide<REPS, Source, TALLY, SPEC>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
 #define CL2_WIDE_PACK(TALLY, SPEC) \
     hipLaunchKernelGGL((k_traverse_wide<1, Source, TALLY, SPEC, true>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
+#define CL2_WIDE_COOP(TALLY, SPEC) \
+    hipLaunchKernelGGL((k_traverse_wide<1, Source, TALLY, SPEC, true, false, true>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
     const bool spec = !((r->debug_flags >> 13) & 1);            // speculative expansion of the stack top (bvh_wide.hpp); bit 13: off
     const bool pack = streams_from_memory && w.tris36 && !((r->debug_flags >> 14) & 1);      // 36-byte triangle records (bvh_wide.hpp); bit 14: off
     if (r->traversal_order != 0) {
@@ -391,11 +393,14 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
         HIP_TRY(r, hipGetLastError());
         return CL2_OK;
     }
-    if (pack) { if (r->counting == 2) { if (spec) CL2_WIDE_PACK(true, true); else CL2_WIDE_PACK(true, false); } else if (spec) CL2_WIDE_PACK(false, true); else CL2_WIDE_PACK(false, false); }
+    const bool coop = pack && !((r->debug_flags >> 15) & 1);     // quad-cooperative node fetch (bvh_wide.hpp); bit 15: off
+    if (coop) { if (r->counting == 2) { if (spec) CL2_WIDE_COOP(true, true); else CL2_WIDE_COOP(true, false); } else if (spec) CL2_WIDE_COOP(false, true); else CL2_WIDE_COOP(false, false); }
+    else if (pack) { if (r->counting == 2) { if (spec) CL2_WIDE_PACK(true, true); else CL2_WIDE_PACK(true, false); } else if (spec) CL2_WIDE_PACK(false, true); else CL2_WIDE_PACK(false, false); }
     else if (streams_from_memory) { if (r->counting == 2) { if (spec) CL2_WIDE(1, true, true); else CL2_WIDE(1, true, false); } else if (spec) CL2_WIDE(1, false, true); else CL2_WIDE(1, false, false); }
     else { if (r->counting == 2) { if (spec) CL2_WIDE(WIDE_TRI_REPS, true, true); else CL2_WIDE(WIDE_TRI_REPS, true, false); } else if (spec) CL2_WIDE(WIDE_TRI_REPS, false, true); else CL2_WIDE(WIDE_TRI_REPS, false, false); }
 #undef CL2_WIDE
 #undef CL2_WIDE_PACK
+#undef CL2_WIDE_COOP
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;
 }

@@ -373,15 +373,16 @@ def test_config5_real_size_vs_oracle(interior_real, oracle_mod):
 def test_config5_packed_triangle_records_are_a_pure_performance_knob(interior_real, oracle_mod):
     """Round 6: the 4-wide walk of a tree that streams from beyond L2 reads 36-byte triangle records ({v0, v1 - v0, v2 - v0}
     without the padding words; csrc/bvh_wide.hpp PACK).  Default on for this 1M-triangle tree; with debug bit 14 the walk reads
-    the 48-byte records of the other walks.  Both -- per-level wide launches (mode 5) and the automatic organisation, with and
-    without the speculative expansion -- give the oracle's subpaths, aggregators, RNG state and ray count over one serial and
+    the 48-byte records of the other walks; and its node records are fetched by quads of lanes together (COOP: 2 L1 look-ups per
+    visit instead of 7; debug bit 15 = every lane for itself).  All of them -- per-level wide launches (mode 5) and the automatic
+    organisation, with and without the speculative expansion -- give the oracle's subpaths, aggregators, RNG state and ray count over one serial and
     two pipelined samples."""
     from clive2_amd.renderer import Renderer, make_seeds
     seeds = make_seeds(interior_real.pixel_width * interior_real.pixel_height)
     o = oracle_mod.OracleRenderer(interior_real, seeds=seeds)
     for _ in range(3):
         o.run_sample()
-    for mode, flags in ((5, 0), (5, 1 << 14), (0, 0), (0, 1 << 14), (5, 1 << 13), (5, (1 << 13) | (1 << 14))):
+    for mode, flags in ((5, 0), (5, 1 << 15), (5, 1 << 14), (0, 0), (0, 1 << 15), (0, 1 << 14), (5, 1 << 13), (5, (1 << 13) | (1 << 15)), (5, (1 << 13) | (1 << 14))):
         r = Renderer(interior_real, seeds=seeds)
         r.set_traversal_mode(mode); r.set_debug_flags(flags)
         r.run_samples(1)
