@@ -57,6 +57,11 @@ IC_GATHER_PEAK_GBS = 8600.0   # scattered lines out of the Infinity Cache (38 MB
 IC_BYTES = 256 << 20
 HBM_ACHIEVABLE_GBS = 6300.0   # what a streaming read gets of the 8 TB/s, same guide, "HBM"
 LINE_BYTES = 128              # one L2 request = one line (tools/l1_gather_rate.hip: a scattered 16-byte load that misses L1 costs a whole line of L2 bandwidth)
+# Vector L1 (TCP) look-up rate: one cache-line look-up per clock and CU; a lane's 16-byte load of its own line is one look-up (lanes of
+# one instruction that share a line are served together).  tools/l1_gather_rate.hip measures 0.92 per clock and CU for 64 scattered lanes.
+N_CU, CLOCK_GHZ = 256, 2.4
+L1_LOOKUP_PEAK_G = N_CU * CLOCK_GHZ
+L1_LOOKUP_MEASURED_PER_CLK = 0.92
 # VALU issue peak: 256 CUs x 4 SIMD-32, a wave64 instruction occupies its SIMD for 2 cycles at 2.4 GHz
 VALU_PEAK_GINST = 1024 * 2.4e9 / 2.0 / 1e9
 
@@ -291,10 +296,14 @@ def pass_fabric(kernels, conn_name, sub_name, sub_launches_per_pass, pass_ms):
 
 
 def mesh_roofline(row, launch_ms, own_bytes, tree_bytes):
-    """What binds a traversal launch whose tree is read through the caches: four fractions, each
+    """What binds a traversal launch whose tree is read through the caches: five fractions (round 6: the L1), each
     `achieved / peak` of one resource, from the committed PMC summary `row` of that kernel (per launch, hash-guarded) and the
     launch time measured live; `bound` = the largest, `frac` = that one.
       valu_issue   SQ_INSTS_VALU wave-instructions / t against 1024 SIMDs x 2.4 GHz / 2 cycles (active lanes beside it)
+      l1_lookups   TCP_TOTAL_CACHE_ACCESSES (cache-line look-ups of the vector L1s: one per 16-byte load of a lane that no other lane of
+                   the instruction shares a line with) / t against one look-up per clock and CU (256 x 2.4 GHz; measured for scattered
+                   loads: 0.92, tools/l1_gather_rate.hip).  Round 6's finding: every mesh walk sits at 0.85-0.89 of it, whatever its
+                   tree size -- a lane reads its 112-byte node with seven loads and a triangle pair with five or six
       l2           what L1 asks of L2: (TCC_HIT + TCC_MISS) requests x 128 B / t against the L2's 34.5 TB/s
       beyond_l2    L2 misses x 128 B / t against the level below: scattered lines out of the Infinity Cache (8.6 TB/s) while
                    the tree fits its 256 MiB, else HBM (6.3 TB/s achievable of 8)
@@ -312,6 +321,12 @@ def mesh_roofline(row, launch_ms, own_bytes, tree_bytes):
         fr["valu_issue"] = {"achieved": round(n_valu / t / 1e9, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s",
                             "frac": round(n_valu / t / 1e9 / VALU_PEAK_GINST, 4), "active_lanes_per_inst": row.get("thread_cycles_per_valu_inst"),
                             "wave_insts_per_launch": n_valu, "wait_share_of_wave_cycles": row.get("wait_share")}
+    n_l1 = row.get("TCP_TOTAL_CACHE_ACCESSES_sum")
+    if n_l1:
+        per_clk = n_l1 / t / 1e9 / L1_LOOKUP_PEAK_G
+        fr["l1_lookups"] = {"achieved": round(n_l1 / t / 1e9, 1), "peak": round(L1_LOOKUP_PEAK_G, 1), "unit": "G look-ups/s", "frac": round(per_clk, 4),
+                            "per_clock_per_cu": round(per_clk, 4), "measured_peak_per_clock_per_cu": L1_LOOKUP_MEASURED_PER_CLK,
+                            "frac_of_measured_peak": round(per_clk / L1_LOOKUP_MEASURED_PER_CLK, 4), "lookups_per_launch": n_l1}
     hit, miss = row.get("TCC_HIT_sum"), row.get("TCC_MISS_sum")
     if hit is not None and miss is not None:
         l2_bytes, below_bytes = (hit + miss) * LINE_BYTES, miss * LINE_BYTES
@@ -337,7 +352,7 @@ def mesh_roofline(row, launch_ms, own_bytes, tree_bytes):
     if not fr:
         return None
     bound = max(fr, key=lambda k: fr[k]["frac"])
-    out = {"bound": {"valu_issue": "valu", "l2": "l2", "beyond_l2": "infinity_cache" if tree_bytes <= IC_BYTES else "hbm", "fabric": "hbm"}[bound],
+    out = {"bound": {"valu_issue": "valu", "l1_lookups": "l1", "l2": "l2", "beyond_l2": "infinity_cache" if tree_bytes <= IC_BYTES else "hbm", "fabric": "hbm"}[bound],
            "bound_fraction": bound, "achieved": fr[bound]["achieved"], "peak": fr[bound]["peak"], "unit": fr[bound]["unit"],
            "frac": fr[bound]["frac"], "fractions": fr}
     if own_bytes:
@@ -351,15 +366,16 @@ def mesh_roofline(row, launch_ms, own_bytes, tree_bytes):
 _SCENES = {}
 
 
-def build_scene(name, W, H, builder=None):
-    """(scene, description) of a bench workload; built once per process (the K = 8 and K = 1 legs share it)."""
-    key = (name, W, H, builder)
+def build_scene(name, W, H, builder=None, max_members=None):
+    """(scene, description) of a bench workload; built once per process (the K = 8 and K = 1 legs share it).  `max_members`: the
+    builder's leaf size (None = the reference's 8; anything else is a labelled experiment, never a bench leg)."""
+    key = (name, W, H, builder) if max_members is None else (name, W, H, builder, max_members)
     if key not in _SCENES:
-        _SCENES[key] = _build_scene(name, W, H, builder)
+        _SCENES[key] = _build_scene(name, W, H, builder, max_members)
     return _SCENES[key]
 
 
-def _build_scene(name, W, H, builder=None):
+def _build_scene(name, W, H, builder=None, max_members=None):
     import numpy as np
     import clive2_amd as c2
     if name == "cornell":
@@ -384,8 +400,8 @@ def _build_scene(name, W, H, builder=None):
         specs = [dict(mesh=(v, f), material=m) for v, f, m in meshes.interior_grid()]
         desc = "Cornell box + 49 x 20,480-tri icospheres (config 5 stand-in)"
     s = c2.create_scene(W, H, np.array([0, 1.5, 6]), np.array([0, 0, -1]), file_specs=specs, materials=mats, room=room,
-                        bvh_builder=builder or os.environ.get("CLIVE2_BENCH_BVH_BUILDER", "auto"))
-    return s, desc + f", {len(s.triangles)} tris / {len(s.boxes)} boxes"
+                        bvh_builder=builder or os.environ.get("CLIVE2_BENCH_BVH_BUILDER", "auto"), max_members=max_members)
+    return s, desc + f", {len(s.triangles)} tris / {len(s.boxes)} boxes" + (f" (max_members {max_members})" if max_members is not None else "")
 
 
 def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world, with_comm, streams=1):

@@ -167,7 +167,7 @@ class _FlatTree:
         self.members = [None] * len(boxes)       # count_boxes() compatibility
 
 
-def _construct_native(root_box, gpu=False, device=0):
+def _construct_native(root_box, gpu=False, device=0, max_members=MAX_MEMBERS):
     """C++ builders of libclive2_amd.so: the host SAH builder (the reference's rule, O(n log n)) or, with `gpu`,
     the PLOC builder on the GPU (another valid tree in the same convention, built in milliseconds)."""
     import ctypes as C
@@ -182,12 +182,12 @@ def _construct_native(root_box, gpu=False, device=0):
     if gpu:
         L.cl2_build_bvh_gpu.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
                                         C.POINTER(C.c_int64), C.c_void_p]
-        rc = L.cl2_build_bvh_gpu(int(device), _native.ptr(tmin), _native.ptr(tmax), n, MAX_MEMBERS, _native.ptr(boxes),
+        rc = L.cl2_build_bvh_gpu(int(device), _native.ptr(tmin), _native.ptr(tmax), n, int(max_members), _native.ptr(boxes),
                                  len(boxes), C.byref(n_boxes), _native.ptr(perm))
     else:
         L.cl2_build_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                     C.POINTER(C.c_int64), C.c_void_p]
-        rc = L.cl2_build_bvh(_native.ptr(tmin), _native.ptr(tmax), n, MAX_MEMBERS, MAX_DEPTH, _native.ptr(boxes),
+        rc = L.cl2_build_bvh(_native.ptr(tmin), _native.ptr(tmax), n, int(max_members), MAX_DEPTH, _native.ptr(boxes),
                              len(boxes), C.byref(n_boxes), _native.ptr(perm))
     if rc != 0:
         raise _native.RendererError(f"cl2_build_bvh{'_gpu' if gpu else ''} failed ({rc}): {L.cl2_last_error(None).decode()}")
@@ -195,7 +195,7 @@ def _construct_native(root_box, gpu=False, device=0):
     return root_box
 
 
-def construct_BVH(root_box, builder="auto"):
+def construct_BVH(root_box, builder="auto", max_members=None):
     """Grow the tree in the reference's order: LIFO work list, right child pushed first,
     and a node becomes a leaf when it has <= MAX_MEMBERS triangles or when MORE than
     MAX_DEPTH nodes are still pending (bvh.py:292-295).  Returns `root_box` with `.tree`.
@@ -203,18 +203,25 @@ def construct_BVH(root_box, builder="auto"):
     builder: "numpy" = this module's restatement (identical to the reference's tree, ties
     included); "native" = the C++ builder in libclive2_amd.so (same rule, O(n log n), equal
     centroids ordered by id); "auto" = native above NATIVE_THRESHOLD triangles; "gpu" = the PLOC builder on the
-    GPU (csrc/bvh_builder_gpu.hip): a different valid tree, for when set-up time matters (needs a GPU)."""
+    GPU (csrc/bvh_builder_gpu.hip): a different valid tree, for when set-up time matters (needs a GPU).
+
+    max_members: the leaf size of the rule above, 1..8 (a leaf record holds at most 8 triangles).  None = the reference's module
+    constant MAX_MEMBERS = 8 (constants.py:28), which is what every default and every figure quoted without a label uses; another
+    value is another INPUT tree (the renderer and the oracle both walk whatever Box[] they are given)."""
+    mm = MAX_MEMBERS if max_members is None else int(max_members)
+    if not 1 <= mm <= 8:
+        raise ValueError("max_members must be 1..8")
     if builder == "gpu":
-        return _construct_native(root_box, gpu=True)
+        return _construct_native(root_box, gpu=True, max_members=mm)
     if builder == "native" or (builder == "auto" and len(root_box) > NATIVE_THRESHOLD):
-        return _construct_native(root_box)
+        return _construct_native(root_box, max_members=mm)
     tree = _Tree(root_box)
     pending = [0]
     deepest = 0
     while pending:
         node = pending.pop()
         deepest = max(deepest, len(pending))
-        if len(tree.members[node]) <= MAX_MEMBERS or len(pending) > MAX_DEPTH:
+        if len(tree.members[node]) <= mm or len(pending) > MAX_DEPTH:
             continue
         l, r = tree.split(node)
         pending += [r, l]

@@ -52,19 +52,6 @@ constexpr int WIDE_STACK_OVERFLOW = 136;      // 2 x the reference's 64-entry st
 __device__ unsigned long long g_walk_histo[6][65];
 #endif
 
-// ---- quad helpers (DPP quad_perm: any permutation inside groups of four adjacent lanes, no LDS) ----
-template <int A> __device__ __forceinline__ int quad_bcast(int v) { return __builtin_amdgcn_mov_dpp(v, A * 85, 0xF, 0xF, true); }         // lane A of the quad
-__device__ __forceinline__ float quad_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }   // [1,0,3,2]
-__device__ __forceinline__ float quad_xor2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); }   // [2,3,0,1]
-// 4 x 4 transpose over (register a, quad lane q): in x_a @ lane q = M[a][q]; out x_k @ lane q = M[q][k].  Two butterfly stages
-// (lane ^ 1 with register ^ 1, then lane ^ 2 with register ^ 2): 8 lane exchanges + 8 selects.  `odd` = q & 1, `hi` = q >> 1.
-__device__ __forceinline__ void quad_transpose(float& x0, float& x1, float& x2, float& x3, bool odd, bool hi) {
-    const float p0 = quad_xor1(x1), p1 = quad_xor1(x0), p2 = quad_xor1(x3), p3 = quad_xor1(x2);
-    const float z0 = odd ? p0 : x0, z1 = odd ? x1 : p1, z2 = odd ? p2 : x2, z3 = odd ? x3 : p3;
-    const float r0 = quad_xor2(z2), r1 = quad_xor2(z3), r2 = quad_xor2(z0), r3 = quad_xor2(z1);
-    x0 = hi ? r0 : z0; x1 = hi ? r1 : z1; x2 = hi ? z2 : r2; x3 = hi ? z3 : r3;
-}
-
 struct WideView {
     const float4* nodes;       // 8 float4 per wide node
     const float4* tris;        // 3 float4 per triangle (the binary walk's array)
@@ -130,16 +117,7 @@ struct WalkTally { unsigned visits = 0, tri_records = 0, spills = 0, bin_nodes =
 // triangles are hit at exactly the same t (the first one visited wins, trace.metal:170) and where a hit lies a few ulp in front
 // of its own leaf box's entry distance (the leaf is then pruned or not depending on what was found before it, trace.metal:152).
 // tests/test_gpu_round6.py counts the rays whose hit differs from the exact walk's.
-// COOP (round 6; streaming trees only; debug bit 15 switches it off): the node record of a lane is fetched by the four lanes of its
-// QUAD together.  Finding: on the 1M-triangle tree the walk is bound by the L1's look-up rate, not by the fabric -- a CU's L1 serves
-// about 0.9 look-ups per clock (tools/l1_gather_rate.hip), a lane that reads its 112-byte node with seven 16-byte loads costs seven
-// look-ups for ONE line, the launch makes 0.85-0.89 look-ups per clock and CU on every mesh config (TCP_TOTAL_CACHE_ACCESSES), and one
-// more 16-byte load of the node's own line per visit costs 6 % of the launch, two 13 % (profiles/r06_l1_lookup_cost.log).  Four
-// adjacent lanes that read 64 contiguous bytes cost ONE look-up (lanes of one instruction that share a line are served together):
-// instruction (a, h) has lane q of every quad load piece 4 h + q of the node of quad lane a -- 8 instructions, 2 look-ups per
-// visit instead of 7 -- and a 4 x 4 transpose over (a, q) by DPP quad permutes hands every lane its own node's pieces, in the same
-// registers the plain loads would have filled.  Same values, same operations on them, same order.
-template <int TRI_REPS, bool TALLY, bool SPEC, bool PACK, bool ORDER, bool COOP, class Source>
+template <int TRI_REPS, bool TALLY, bool SPEC, bool PACK, bool ORDER, class Source>
 __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, const BvhView& b, unsigned n, unsigned* work_counter, const Source& src, WalkTally& tally) {
     constexpr bool TWO_TRIS = true;
     extern __shared__ float4 cl2_tree_lds[];
@@ -270,43 +248,9 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
         h_node = visit;
 #endif
         if (__any(visit)) {
-            float4 c0, c1, c2, c3, c4, c5, c6;                              // COOP: the lane's node, pieces 0..6, fetched by its quad
-            if (COOP) {
-                const int vn = visit ? ((SPEC && spec) ? spec_ref : cur) : -1;
-                const int gn = (vn >= n_win) ? vn : -1;                     // nodes of the LDS window are not fetched
-                if (__any(gn >= 0)) {
-                    const unsigned q16 = (unsigned)(tid & 3) * 16u;
-                    const int n0 = quad_bcast<0>(gn), n1 = quad_bcast<1>(gn), n2 = quad_bcast<2>(gn), n3 = quad_bcast<3>(gn);
-                    const char* __restrict__ base = reinterpret_cast<const char*>(w.nodes);
-                    float4 d0, d1, d2, d3;                                  // pieces 4..7 of the four nodes (c0..c3: pieces 0..3)
-                    // a lane whose quad mate does not visit keeps whatever these registers hold: nobody reads it.  (Defined by an
-                    // empty asm: left formally uninitialised the compiler keeps them in scratch memory and waits for every load pair.)
-#define CL2_ANY4(V) asm volatile("" : "=v"(V.x), "=v"(V.y), "=v"(V.z), "=v"(V.w))
-                    CL2_ANY4(c0); CL2_ANY4(c1); CL2_ANY4(c2); CL2_ANY4(c3); CL2_ANY4(d0); CL2_ANY4(d1); CL2_ANY4(d2); CL2_ANY4(d3);
-#undef CL2_ANY4
-                    if (n0 >= 0) { const unsigned o0 = (unsigned)n0 * 128u + q16; c0 = *reinterpret_cast<const float4*>(base + o0); d0 = *reinterpret_cast<const float4*>(base + o0 + 64u); }
-                    if (n1 >= 0) { const unsigned o1 = (unsigned)n1 * 128u + q16; c1 = *reinterpret_cast<const float4*>(base + o1); d1 = *reinterpret_cast<const float4*>(base + o1 + 64u); }
-                    if (n2 >= 0) { const unsigned o2 = (unsigned)n2 * 128u + q16; c2 = *reinterpret_cast<const float4*>(base + o2); d2 = *reinterpret_cast<const float4*>(base + o2 + 64u); }
-                    if (n3 >= 0) { const unsigned o3 = (unsigned)n3 * 128u + q16; c3 = *reinterpret_cast<const float4*>(base + o3); d3 = *reinterpret_cast<const float4*>(base + o3 + 64u); }
-                    const bool odd = (tid & 1) != 0, hi = (tid & 2) != 0;
-                    // (scheduling fences: left alone the scheduler starts all eight transposes at once and their temporaries spill)
-                    quad_transpose(c0.x, c1.x, c2.x, c3.x, odd, hi); quad_transpose(c0.y, c1.y, c2.y, c3.y, odd, hi);
-                    __builtin_amdgcn_sched_barrier(0);
-                    quad_transpose(c0.z, c1.z, c2.z, c3.z, odd, hi); quad_transpose(c0.w, c1.w, c2.w, c3.w, odd, hi);
-                    __builtin_amdgcn_sched_barrier(0);
-                    quad_transpose(d0.x, d1.x, d2.x, d3.x, odd, hi); quad_transpose(d0.y, d1.y, d2.y, d3.y, odd, hi);
-                    __builtin_amdgcn_sched_barrier(0);
-                    quad_transpose(d0.z, d1.z, d2.z, d3.z, odd, hi); quad_transpose(d0.w, d1.w, d2.w, d3.w, odd, hi);
-                    __builtin_amdgcn_sched_barrier(0);
-                    c4 = d0; c5 = d1; c6 = d2;                              // (piece 7 is padding)
-                }
-            }
             if (visit) {
                 float4 lx, ly, lz, hx, hy, hz, rf;
                 const int vnode = (SPEC && spec) ? spec_ref : cur;
-                if (COOP && !(n_win > 0 && vnode < n_win)) {
-                    lx = c0; ly = c1; lz = c2; hx = c3; hy = c4; hz = c5; rf = c6;
-                } else
                 if (n_win > 0 && vnode < n_win) {
                     const float4* nd = s_nodes + 8 * vnode;
                     lx = nd[0]; ly = nd[1]; lz = nd[2]; hx = nd[3]; hy = nd[4]; hz = nd[5]; rf = nd[6];
@@ -413,15 +357,18 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
                 tri_i = i1 + 1;
                 if (TALLY) tally.tri_records += (i1 != i0) ? 2u : 1u;
                 if (PACK) {
+                    // the pair as ONE run of 72 bytes (five loads instead of six: what binds this walk is the L1's look-up rate, one
+                    // look-up per 16-byte load of a lane, profiles/r06_l1_lookup_cost.log).  A leaf's last odd triangle has no
+                    // partner: the record behind it (the next leaf's first triangle; the array ends in one record of padding) is
+                    // loaded and its test masked out -- where the 48-byte form re-tests the same triangle, which cannot pass twice.
                     const float* __restrict__ ta = w.tris36 + (size_t)9 * i0;
-                    const float* __restrict__ tb = w.tris36 + (size_t)9 * i1;
-                    float a[9], c[9];
+                    float a[18];
 #pragma unroll
-                    for (int k = 0; k < 9; k++) a[k] = ta[k];
-#pragma unroll
-                    for (int k = 0; k < 9; k++) c[k] = tb[k];
+                    for (int k = 0; k < 18; k++) a[k] = ta[k];
                     tri_test_branchless(o, d, make_float4(a[0], a[1], a[2], 0.0f), make_float4(a[3], a[4], a[5], 0.0f), make_float4(a[6], a[7], a[8], 0.0f), i0, best);
-                    tri_test_branchless(o, d, make_float4(c[0], c[1], c[2], 0.0f), make_float4(c[3], c[4], c[5], 0.0f), make_float4(c[6], c[7], c[8], 0.0f), i1, best);
+                    Hit second = best;
+                    tri_test_branchless(o, d, make_float4(a[9], a[10], a[11], 0.0f), make_float4(a[12], a[13], a[14], 0.0f), make_float4(a[15], a[16], a[17], 0.0f), i0 + 1, second);
+                    if (i1 != i0) best = second;
                 } else {
                     const float4* __restrict__ ta = w.tris + (size_t)3 * i0;
                     const float4* __restrict__ tb = w.tris + (size_t)3 * i1;

@@ -321,13 +321,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(78))) void k_
 // (The ray tally is added BEFORE the walk: `threadIdx.x == 0` after it would keep the thread index alive through the whole loop,
 // in a kernel held to 64 VGPRs -- round 4's builds spilled exactly that register to scratch at entry and reloaded it at exit.)
 // The tallying variant (cl2_set_counting(2), never timed) carries four more counters per lane and takes 6 waves per SIMD.
-#ifndef CL2_COOP_WAVES
-#define CL2_COOP_WAVES 6
-#endif
-// (COOP: the streaming trees' launches run six workgroups per CU anyway -- 16 KB of stack + the 8 KB window of 64 nodes per
-// workgroup -- so the quad-cooperative fetch may take the 80 registers of six waves per SIMD for its eight loads in flight)
-template <int TRI_REPS, class Source, bool TALLY = false, bool SPEC = false, bool PACK = false, bool ORDER = false, bool COOP = false>
-__global__ __launch_bounds__(BLOCK, COOP ? CL2_COOP_WAVES : TALLY ? 6 : 8) __attribute__((amdgpu_num_sgpr(80))) void k_traverse_wide(WideView wide, BvhView bvh, const unsigned* __restrict__ count,
+template <int TRI_REPS, class Source, bool TALLY = false, bool SPEC = false, bool PACK = false, bool ORDER = false>
+__global__ __launch_bounds__(BLOCK, TALLY ? 6 : 8) __attribute__((amdgpu_num_sgpr(80))) void k_traverse_wide(WideView wide, BvhView bvh, const unsigned* __restrict__ count,
                                                         unsigned* __restrict__ work_counter, Source src, Stats* stats, int is_conn) {
     const unsigned n = *count;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -336,7 +331,7 @@ __global__ __launch_bounds__(BLOCK, COOP ? CL2_COOP_WAVES : TALLY ? 6 : 8) __att
         if (TALLY) atomicAdd(&stats->walk[is_conn ? 1 : 0][0], (unsigned long long)n);
     }
     WalkTally tally;
-    traverse_wide_persistent<TRI_REPS, TALLY, SPEC, PACK, ORDER, COOP>(wide, bvh, n, work_counter, src, tally);
+    traverse_wide_persistent<TRI_REPS, TALLY, SPEC, PACK, ORDER>(wide, bvh, n, work_counter, src, tally);
     if (TALLY) {
         unsigned v[4] = {tally.visits, tally.tri_records, tally.spills, tally.bin_nodes};
         for (int off = 32; off > 0; off >>= 1)

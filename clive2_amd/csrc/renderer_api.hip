@@ -374,33 +374,22 @@ int launch_wide(cl2_renderer* r, hipStream_t st, int stage, const unsigned* coun
     // the binary records (lanes whose ray has a non-finite 1/d) come through the caches: no window for them
     BvhView b = r->bvh;
     b.n_lds_nodes = 0; b.lds_tris = 0; b.n_fast_nodes = 0;
-#define CL2_WIDE(REPS, TALLY, SPEC) \
-    hipLaunchKernelGGL((k_traverse_wide<REPS, Source, TALLY, SPEC>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
-#define CL2_WIDE_PACK(TALLY, SPEC) \
-    hipLaunchKernelGGL((k_traverse_wide<1, Source, TALLY, SPEC, true>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
-#define CL2_WIDE_COOP(TALLY, SPEC) \
-    hipLaunchKernelGGL((k_traverse_wide<1, Source, TALLY, SPEC, true, false, true>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
+#define CL2_WIDE(REPS, TALLY, SPEC, PACK, ORDER) \
+    hipLaunchKernelGGL((k_traverse_wide<REPS, Source, TALLY, SPEC, PACK, ORDER>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
+// (a macro argument may not be a run-time value: one dispatch level per template parameter)
+#define CL2_WIDE_BY_SPEC(REPS, TALLY, PACK) do { if (spec) CL2_WIDE(REPS, TALLY, true, PACK, false); else CL2_WIDE(REPS, TALLY, false, PACK, false); } while (0)
+#define CL2_WIDE_BY_TALLY(REPS, PACK) do { \
+        if (r->traversal_order != 0) { if (r->counting == 2) CL2_WIDE(REPS, true, true, PACK, true); else CL2_WIDE(REPS, false, true, PACK, true); } \
+        else if (r->counting == 2) CL2_WIDE_BY_SPEC(REPS, true, PACK); else CL2_WIDE_BY_SPEC(REPS, false, PACK); } while (0)
     const bool spec = !((r->debug_flags >> 13) & 1);            // speculative expansion of the stack top (bvh_wide.hpp); bit 13: off
-    const bool pack = streams_from_memory && w.tris36 && !((r->debug_flags >> 14) & 1);      // 36-byte triangle records (bvh_wide.hpp); bit 14: off
-    if (r->traversal_order != 0) {
-        // opt-in nearest-first child order (cl2_set_traversal_order; NOT the parity path): the speculative walk only
-#define CL2_WIDE_ORDER(REPS, TALLY, PACK) \
-    hipLaunchKernelGGL((k_traverse_wide<REPS, Source, TALLY, true, PACK, true>), dim3(grid), dim3(BLOCK), lds, st, w, b, count, work_counter, src, r->d_stats, is_conn)
-        if (pack) { if (r->counting == 2) CL2_WIDE_ORDER(1, true, true); else CL2_WIDE_ORDER(1, false, true); }
-        else if (streams_from_memory) { if (r->counting == 2) CL2_WIDE_ORDER(1, true, false); else CL2_WIDE_ORDER(1, false, false); }
-        else { if (r->counting == 2) CL2_WIDE_ORDER(WIDE_TRI_REPS, true, false); else CL2_WIDE_ORDER(WIDE_TRI_REPS, false, false); }
-#undef CL2_WIDE_ORDER
-        HIP_TRY(r, hipGetLastError());
-        return CL2_OK;
-    }
-    const bool coop = pack && !((r->debug_flags >> 15) & 1);     // quad-cooperative node fetch (bvh_wide.hpp); bit 15: off
-    if (coop) { if (r->counting == 2) { if (spec) CL2_WIDE_COOP(true, true); else CL2_WIDE_COOP(true, false); } else if (spec) CL2_WIDE_COOP(false, true); else CL2_WIDE_COOP(false, false); }
-    else if (pack) { if (r->counting == 2) { if (spec) CL2_WIDE_PACK(true, true); else CL2_WIDE_PACK(true, false); } else if (spec) CL2_WIDE_PACK(false, true); else CL2_WIDE_PACK(false, false); }
-    else if (streams_from_memory) { if (r->counting == 2) { if (spec) CL2_WIDE(1, true, true); else CL2_WIDE(1, true, false); } else if (spec) CL2_WIDE(1, false, true); else CL2_WIDE(1, false, false); }
-    else { if (r->counting == 2) { if (spec) CL2_WIDE(WIDE_TRI_REPS, true, true); else CL2_WIDE(WIDE_TRI_REPS, true, false); } else if (spec) CL2_WIDE(WIDE_TRI_REPS, false, true); else CL2_WIDE(WIDE_TRI_REPS, false, false); }
+    // 36-byte triangle records, a pair fetched as one run of 72 bytes (bvh_wide.hpp: PACK); bit 14: the 48-byte records of the other
+    // walks.  The opt-in nearest-first child order (cl2_set_traversal_order; NOT the parity path) exists for the speculative walk only.
+    const bool pack = w.tris36 && !((r->debug_flags >> 14) & 1);
+    if (streams_from_memory) { if (pack) CL2_WIDE_BY_TALLY(1, true); else CL2_WIDE_BY_TALLY(1, false); }
+    else { if (pack) CL2_WIDE_BY_TALLY(WIDE_TRI_REPS, true); else CL2_WIDE_BY_TALLY(WIDE_TRI_REPS, false); }
+#undef CL2_WIDE_BY_TALLY
+#undef CL2_WIDE_BY_SPEC
 #undef CL2_WIDE
-#undef CL2_WIDE_PACK
-#undef CL2_WIDE_COOP
     HIP_TRY(r, hipGetLastError());
     return CL2_OK;
 }
@@ -1165,10 +1154,9 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     r->wide.tris36 = nullptr;
     r->n_wide = 0;
     if (n_wide > 0) {
-        // a tree that streams from beyond L2 (the size rule of two_tris_per_step_plain): its wide walk reads the triangle records
-        // without their three padding words (36 bytes each; bvh_wide.hpp, PACK)
-        if ((size_t)n_records * 32 + (size_t)n_tris * 48 > ((size_t)16 << 20)) {
-            std::vector<float> h36((size_t)9 * n_tris);
+        // the wide walk reads the triangle records without their three padding words (36 bytes each; bvh_wide.hpp, PACK)
+        {
+            std::vector<float> h36((size_t)9 * n_tris + 9, 0.0f);          // + one record of padding: the pair load of the last triangle reads it
             for (int t = 0; t < n_tris; t++)
                 for (int v = 0; v < 3; v++) {
                     const float4 q = h_tris[3 * (size_t)t + v];

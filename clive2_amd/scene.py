@@ -68,10 +68,11 @@ class Scene:
 
 
 def create_scene(pixel_width=1280, pixel_height=720, cam_center=ZERO_VECTOR, cam_direction=UNIT_Z,
-                 file_specs=None, materials=None, verbose=False, bvh_builder="auto", room=None):
+                 file_specs=None, materials=None, verbose=False, bvh_builder="auto", room=None, max_members=None):
     """scene.py:21-104.  Extensions: `materials` (table override), `"mesh": (vertices, faces)` file specs,
     `bvh_builder`, and `room` -- the enclosure as a list of load.Triangle objects in place of the
-    Cornell box of load.triangles_for_box() (e.g. a subset of it: an open scene; it must keep an emitter)."""
+    Cornell box of load.triangles_for_box() (e.g. a subset of it: an open scene; it must keep an emitter); `max_members` -- the
+    builder's leaf size (None = the reference's constant 8, constants.py:28; bvh.construct_BVH)."""
     camera = Camera(center=cam_center, direction=cam_direction, pixel_width=pixel_width,
                     pixel_height=pixel_height, phys_width=pixel_width / pixel_height, phys_height=1)
     soups = [FastTreeBox.from_triangle_objects(camera_geometry(camera) + (triangles_for_box() if room is None else list(room)))]
@@ -90,7 +91,7 @@ def create_scene(pixel_width=1280, pixel_height=720, cam_center=ZERO_VECTOR, cam
     soup = FastTreeBox.concat(soups) if len(soups) > 1 else soups[0]
 
     t0 = time.time()
-    boxes, tris = np_flatten_bvh(construct_BVH(soup, builder=bvh_builder))
+    boxes, tris = np_flatten_bvh(construct_BVH(soup, builder=bvh_builder, max_members=max_members))
     if verbose:
         print(f"BVH construction took {time.time() - t0:.4f} seconds")
 

@@ -285,10 +285,8 @@ int cl2_read_walk_tallies(cl2_renderer* r, cl2_walk_tallies* out);
  *   bit 12      invert the one/two-triangles-per-step choice of the persistent walk
  *   bit 13      4-wide walk WITHOUT the speculative expansion of the stack top (round 5: a lane that is testing triangles expands
  *               the wide node on top of its stack in the same pass, csrc/bvh_wide.hpp): the pass as round 4 had it, for A/B runs and tests
- *   bit 14      4-wide walk of a tree that streams from beyond L2 (> 16 MB) with the 48-byte triangle records of the other walks
- *               instead of its 36-byte ones (round 6, csrc/bvh_wide.hpp: PACK), for A/B runs and tests
- *   bit 15      4-wide walk of such a tree WITHOUT the quad-cooperative node fetch (round 6, csrc/bvh_wide.hpp: COOP): every lane
- *               reads its node with seven 16-byte loads of its own, as the cache-resident trees' walk does
+ *   bit 14      4-wide walk with the 48-byte triangle records of the other walks (six 16-byte loads per pair) instead of its own
+ *               36-byte ones, a pair fetched as one run of 72 bytes (five loads; round 6, csrc/bvh_wide.hpp: PACK), for A/B runs and tests
  *   bits 16-19  accepted and ignored (round 3: stack entries per lane in LDS of the 4-wide walk; a compile-time 8 since round 4)
  *   bits 20-23  4-wide walk: LDS window of the top of the wide tree in units of 32 nodes (0 = by tree size: 32 nodes, 64 when
  *               the tree streams from memory; 15 = no window)
@@ -296,7 +294,7 @@ int cl2_read_walk_tallies(cl2_renderer* r, cl2_walk_tallies* out);
  * (libclive2_amd_test.so, -DCL2_TEST_VARIANT), where they switch parts of the resolve stage off for timing
  * dissections -- bit 0 the t = 1 splat atomics, bit 1 / bit 2 the t >= 2 / t == 1 strategy pairs -- and make the
  * render INVALID; the shipped library refuses them. */
-#define CL2_DEBUG_KNOWN_BITS 0x00FFFFFF
+#define CL2_DEBUG_KNOWN_BITS 0x00FF7FFF
 int cl2_set_debug_flags(cl2_renderer* r, int flags);
 /* Reproducible light image, off by default.  The reference's light-image chain (sort by target pixel, per-pixel gather:
  * src/renderer.py:97-111, :213-250, src/trace.metal:872-964) is deterministic; the float atomics that replace it add a pixel's

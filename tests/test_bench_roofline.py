@@ -30,6 +30,12 @@ def test_mesh_roofline_names_the_largest_fraction():
     assert r2["fractions"]["fabric"]["decided_by"].startswith("request-size") and abs(r2["frac"] - (30e9 + 5e4 * 1024) / 5e-3 / 1e9 / 8000.0) < 1e-3
     assert r2["fractions"]["beyond_l2"]["peak"] == bench.HBM_ACHIEVABLE_GBS         # a tree beyond the Infinity Cache: HBM's rate
     assert bench.mesh_roofline(None, 5.0, None, 1) is None and bench.mesh_roofline(row, 0.0, None, 1) is None
+    # round 6: the vector L1's look-up rate (TCP_TOTAL_CACHE_ACCESSES against one look-up per clock and CU) -- where it is the largest
+    # fraction the launch is bound by it: 2.7e9 look-ups in 5 ms on 256 CUs = 0.879 per clock and CU
+    row3 = dict(row, TCP_TOTAL_CACHE_ACCESSES_sum=2.7e9)
+    r3 = bench.mesh_roofline(row3, 5.0, None, 4 << 20)
+    assert r3["bound"] == "l1" and r3["bound_fraction"] == "l1_lookups" and set(r3["fractions"]) == {"valu_issue", "l1_lookups", "l2", "beyond_l2", "fabric"}
+    assert abs(r3["frac"] - 2.7e9 / 5e-3 / (256 * 2.4e9)) < 1e-3 and r3["fractions"]["l1_lookups"]["frac_of_measured_peak"] > r3["frac"]
 
 
 def test_committed_pmc_summaries_belong_to_the_kernel_sources_in_the_tree():
