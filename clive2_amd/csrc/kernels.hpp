@@ -850,6 +850,20 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void k_subpaths_persistent(
                 const int i1 = two ? i0 + 1 : i0;
                 tri_i = i1 + 1;
                 float4 a0, a1, a2, c0, c1, c2;
+                if (WIDE && TWO_TRIS && wide.tris36) {
+                    // 36-byte records, the pair as one run of 72 bytes: five L1 look-ups instead of six (bvh_wide.hpp: PACK); the
+                    // record behind a leaf's last odd triangle is loaded and its test masked out
+                    const float* __restrict__ ta = wide.tris36 + (size_t)9 * i0;
+                    float a[18];
+#pragma unroll
+                    for (int k = 0; k < 18; k++) a[k] = ta[k];
+                    if (COUNT) n_tri += two ? 2 : 1;
+                    tri_test_branchless(o, d, make_float4(a[0], a[1], a[2], 0.0f), make_float4(a[3], a[4], a[5], 0.0f), make_float4(a[6], a[7], a[8], 0.0f), i0, best);
+                    Hit second = best;
+                    tri_test_branchless(o, d, make_float4(a[9], a[10], a[11], 0.0f), make_float4(a[12], a[13], a[14], 0.0f), make_float4(a[15], a[16], a[17], 0.0f), i0 + 1, second);
+                    if (two) best = second;
+                    continue;
+                }
                 if (b.lds_tris) {
                     a0 = s.tris[3 * i0]; a1 = s.tris[3 * i0 + 1]; a2 = s.tris[3 * i0 + 2];
                     if (TWO_TRIS) { c0 = s.tris[3 * i1]; c1 = s.tris[3 * i1 + 1]; c2 = s.tris[3 * i1 + 2]; }

@@ -487,6 +487,7 @@ int launch_subpaths(cl2_renderer* r, hipStream_t st, const PathBufs* set, int ki
         w.ovf_stride = std::max(r->wide_ovf_entries, 1);
         w.overflow = r->d_wide_ovf;                            // stage 0 region: the subpath stage
     }
+    if ((r->debug_flags >> 14) & 1) w.tris36 = nullptr;         // bit 14: the 48-byte triangle records (bvh_wide.hpp: PACK off)
     const size_t lds = widew ? (size_t)w.stack_lds * BLOCK * 8 + (size_t)w.n_lds_nodes * 128 : bvh_lds_bytes(r);
     // register budget: 5 waves per SIMD (102 VGPRs: the bounce code; 6 waves cost 64 bytes of scratch per lane and measured
     // 13.0 -> 13.6 ms on the glass scene, 8 waves 24.5 ms); the grid holds as many workgroups as stay resident
