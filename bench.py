@@ -404,7 +404,7 @@ def _build_scene(name, W, H, builder=None, max_members=None):
     return s, desc + f", {len(s.triangles)} tris / {len(s.boxes)} boxes" + (f" (max_members {max_members})" if max_members is not None else "")
 
 
-def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world, with_comm, streams=1):
+def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world, with_comm, streams=1, order=0):
     """Warm-up (tuner + counting pass), the timed region, a serial per-stage breakdown.  `steps` = samples THIS
     rank renders inside the clock; with `streams` = K sample streams (cl2_set_sample_streams: K independent samples of the
     frame per pass, one seed buffer each) that is ceil(steps / K) passes.  Returns the pieces of the JSON line that depend
@@ -442,6 +442,8 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
         r.synchronize()
 
     r.set_levels_per_launch(args.levels_per_launch)
+    if order:
+        r.set_traversal_order(order)             # opt-in nearest-first child order: labelled extras of the detail file only, never a leg's figure
     r.set_traversal_mode(args.traversal_mode)
     r.set_pipelining(args.pipelining)
     if args.debug_flags:
@@ -638,6 +640,13 @@ def mesh_leg(args, key, name, W, H, n_steps, streams, local_rank):
                                  "active_lanes_per_valu_inst": m1["roofline"].get("active_lanes_per_valu_inst"),
                                  "avg_launch_ms": m1["roofline"]["avg_launch_ms"], "paths_share": m1["paths_share"]}
         leg["serial_run_sample_ms"] = serial_loop(name, W, H, local_rank)
+        if not args.no_order_extra:
+            # a labelled extra, never the leg's figure: the same workload with the opt-in nearest-first child order of the 4-wide walks
+            # (cl2_set_traversal_order(1): NOT bit-exact by construction -- tests/test_gpu_fullsize.py counts the rays whose hit differs)
+            mo = run_workload(args, name, W, H, max(streams, n_steps // 2), 2, 0, local_rank, 1, with_comm=False, streams=streams, order=1)
+            leg["nearest_first_extra"] = {"label": "opt-in cl2_set_traversal_order(1): nearest child first, NOT bit-exact (exact-t ties); not the leg's figure",
+                                          "mrays_per_s": round(mo["rays_total"] / mo["dt"] / 1e6, 2), "ms_per_step": round(mo["dt"] / mo["steps_rank"] * 1e3, 3),
+                                          "sample_streams": streams, "steps": mo["steps_rank"]}
     except Exception as exc:                                   # noqa: BLE001
         print(f"bench.py: leg {key} failed: {exc!r}", file=sys.stderr)
         leg["error"] = repr(exc)[:300]
@@ -833,6 +842,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-order-extra", action="store_true", help="skip the labelled nearest-first extras of the mesh legs (detail file only)")
     ap.add_argument("--no-mesh", action="store_true", help="skip the mesh workloads (config 3 / 4 / 5 stand-ins) and the serial-loop figures of the N=1 line")
     ap.add_argument("--sample-streams", type=int, default=1,
                     help="sample streams of the headline workload (K independent samples of the frame per pass, cl2_set_sample_streams); "

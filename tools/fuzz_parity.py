@@ -19,7 +19,7 @@ from clive2_amd.renderer import Renderer, make_seeds
 from oracle import oracle as orc
 
 
-def random_scene(rng):
+def random_scene(rng, max_members=None):
     w, h = int(rng.randint(17, 120)), int(rng.randint(11, 80))
     mats = np.zeros(12, dtype=st.Material)
     mats[:8] = get_materials()
@@ -44,8 +44,8 @@ def random_scene(rng):
     if rng.rand() < 0.3:                    # an open scene: the emitter and a random subset of the walls
         box = triangles_for_box()
         room = [t for t in box if t.emitter or rng.rand() < 0.5]
-    return (c2.create_scene(w, h, center, direction, file_specs=specs, materials=mats, bvh_builder=str(builder), room=room),
-            (w, h, len(specs), str(builder), 'open' if room is not None else 'closed'))
+    return (c2.create_scene(w, h, center, direction, file_specs=specs, materials=mats, bvh_builder=str(builder), room=room, max_members=max_members),
+            (w, h, len(specs), str(builder), 'open' if room is not None else 'closed') + ((f"mm{max_members}",) if max_members else ()))
 
 
 def main():
@@ -55,7 +55,9 @@ def main():
     bad = 0
     for k in range(first, first + n):
         rng = np.random.RandomState(1000 + k)
-        scene, desc = random_scene(rng)
+        # round 6: every fifth scene is built with another leaf size (create_scene(max_members=...): 4, 2 or 1 instead of the reference's 8;
+        # taken from the scene number, not from the generator, so that the scenes themselves stay what earlier rounds rendered)
+        scene, desc = random_scene(rng, max_members=(4, 2, 1)[(k // 5) % 3] if k % 5 == 4 else None)
         B = scene.pixel_width * scene.pixel_height
         mode, levels, stages = int(rng.randint(0, 6)), int(rng.randint(0, 7)), int(rng.randint(-1, 3))
         flags = 0
@@ -75,6 +77,10 @@ def main():
         if rng.rand() < 0.3:
             flags |= 1 << 13
         repro = bool(rng.rand() < 0.4)
+        # round 6: the 4-wide walks read 36-byte triangle records, a pair as one run of 72 bytes; bit 14 = the 48-byte records (drawn
+        # after everything else, so that earlier rounds' scenes keep their settings)
+        if rng.rand() < 0.3:
+            flags |= 1 << 14
         seeds = [make_seeds(B, seed=k, rank=j) for j in range(K)]
         r = Renderer(scene, seeds=seeds[0] if K == 1 else np.stack(seeds), streams=K)
         os_ = [orc.OracleRenderer(scene, seeds=sd) for sd in seeds]
