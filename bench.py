@@ -30,8 +30,9 @@ Instruction counts and HBM bytes per launch come from committed rocprofv3 PMC pa
 marked "static" (used only while the kernel sources still hash to what was profiled).
 The mesh legs -- `roofline_mesh` (config 3), `roofline_blob` (config 4), `roofline_hbm` (config 5 at 1080p) and
 `roofline_hbm_4k` (config 5 at its own 3840 x 2160) -- read their tree through the caches, and say WHICH resource binds the
-launch: every one of them carries `fractions` = {valu_issue, l2, beyond_l2, fabric} (mesh_roofline below), `bound` names the
-largest and `frac` is that one (<= 1).  SURVEY 8(d)'s formula figure (the reference's binary walk, 32 B per node test + 36 B
+launch: every one of them carries `fractions` = {valu_issue, l1_lookups, l2, beyond_l2, fabric} (mesh_roofline below), `bound` names the
+largest and `frac` is that one (<= 1).  Round 6: stdout carries ONE line of at most 4,000 characters (compact_line: the contract's keys,
+`roofline`, `cpu_baseline`, one compact `legs` object); the full result with every fraction goes to bench_detail.json beside this script.  SURVEY 8(d)'s formula figure (the reference's binary walk, 32 B per node test + 36 B
 per triangle test) is kept beside them as `contract_algorithmic_gbs` with `served_from`: it prices bytes the 4-wide walk does
 not read, against a level they are not served from, and is not a fraction of anything.  The stage-share tuner of the mesh
 scenes (cl2_tune) runs in the warm-up, never inside the clock.  `serial_run_sample_ms` times the reference's own loop --
@@ -310,7 +311,7 @@ def mesh_roofline(row, launch_ms, own_bytes, tree_bytes):
       fabric       FETCH_SIZE + WRITE_SIZE as reported (raw) and with the guide's x2 on FETCH_SIZE (calibrated on coalesced
                    16 B / lane streams; these are scattered 112-byte node and 48-byte triangle reads: both shown) against the
                    8 TB/s HBM peak; the fraction that decides is the x2 one (the larger)
-    `own_bytes`: what the walk ITSELF asks of L1 per launch (device tallies: 112 B per wide node + 48 B per triangle record +
+    `own_bytes`: what the walk ITSELF asks of L1 per launch (device tallies: 112 B per wide node + 36 B per triangle record +
     48 B per ray), reported with the share of it that L1 passes on."""
     if not row or launch_ms <= 0:
         return None
@@ -558,14 +559,14 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
             def own_bytes(tally, rays_launch):
                 if not tally or not tally["rays"]:
                     return None
-                per_ray = (112.0 * tally["wide_visits"] + 48.0 * tally["tri_records"] + 32.0 * tally["binary_records"]
+                per_ray = (112.0 * tally["wide_visits"] + 36.0 * tally["tri_records"] + 32.0 * tally["binary_records"]
                            + 16.0 * tally["stack_spills"]) / tally["rays"] + 48.0
                 return {"bytes_per_ray": round(per_ray, 1), "bytes_per_launch": round(per_ray * rays_launch),
                         "wide_visits_per_ray": round(tally["wide_visits"] / tally["rays"], 3),
                         "tri_records_per_ray": round(tally["tri_records"] / tally["rays"], 3),
                         "stack_spills_per_ray": round(tally["stack_spills"] / tally["rays"], 4),
                         "binary_records_per_ray": round(tally["binary_records"] / tally["rays"], 4),
-                        "formula": "112 B x wide-node visits + 48 B x triangle records + 32 B x binary records + 16 B x stack spills (write + read) + 48 B per ray (device tallies, cl2_set_counting(2))"}
+                        "formula": "112 B x wide-node visits + 36 B x triangle records (round 6: the walk's own 36-byte records) + 32 B x binary records + 16 B x stack spills (write + read) + 48 B per ray (device tallies, cl2_set_counting(2))"}
             tree = org["tree_bytes"]
             roof = mesh_roofline(pmc, avg_ms, own_bytes(own and own["connection"], rays_per_launch), tree)
             alone = mesh_roofline(pmc, alone_ms, None, tree)

@@ -126,7 +126,7 @@ def walk_cost(scene, order, K=8, passes=3):
         def per_ray(x):
             n = max(x["rays"], 1)
             return {"wide_visits": round(x["wide_visits"] / n, 3), "tri_records": round(x["tri_records"] / n, 3),
-                    "own_bytes": round((112.0 * x["wide_visits"] + 48.0 * x["tri_records"] + 32.0 * x["binary_records"] + 16.0 * x["stack_spills"]) / n + 48.0, 1)}
+                    "own_bytes": round((112.0 * x["wide_visits"] + 36.0 * x["tri_records"] + 32.0 * x["binary_records"] + 16.0 * x["stack_spills"]) / n + 48.0, 1)}
         return {"order": order, "ms_per_sample": round(dt / (passes * K) * 1e3, 3), "serial_stage_ms_per_sample": stages,
                 "connection": per_ray(t["connection"]), "subpath": per_ray(t["subpath"]), "rays_per_sample": c["rays"] // K,
                 "paths_share": r.organisation()["paths_share"]}
