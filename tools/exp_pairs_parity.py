@@ -1,4 +1,4 @@
-"""Parity of the two-lanes-per-ray walk (debug bit 15, csrc/bvh_wide2.hpp) against the ORACLE before it is timed:
+"""(Needs profiles/r06_two_lanes_per_ray.patch applied.)  Parity of the two-lanes-per-ray walk (debug bit 15, csrc/bvh_wide2.hpp) against the ORACLE before it is timed:
     [CL2_LIB=build/lib_x.so] python tools/exp_pairs_parity.py
 config-3 geometry (modes 5 and 0, speculation on and off), the 20k-triangle blob, an open scene, a ragged frame, the 1M-triangle
 interior (the streaming form: one pair round per pass), config 3 at 1080p (one serial + two pipelined samples, 4 sample streams),
