@@ -257,3 +257,32 @@ def test_scene_from_a_fixture_mesh_file():
     scene = c2.create_scene(32, 24, np.array([0, 1.5, 6]), np.array([0, 0, -1]),
                             file_specs=[dict(file_path=os.path.join(MESHES, "tetra_big_endian.ply"), material=5, scale=2.0)])
     assert len(scene.triangles) == 16 + 4 and scene.validate()
+
+
+@pytest.mark.parametrize("builder", ["numpy", "native"])
+@pytest.mark.parametrize("max_members", [1, 2, 4])
+def test_leaf_size_is_an_input_of_create_scene(builder, max_members):
+    """Round 6: `create_scene(max_members=...)` -- the builder's leaf size, the reference's module constant 8
+    (constants.py:28) by default.  Every leaf holds at most that many triangles, every triangle sits in exactly one leaf, children
+    nest in their parents (what the exact 4-wide walk needs), and values outside 1..8 are refused."""
+    import clive2_amd as c2
+    from clive2_amd.meshes import icosphere
+    v, f = icosphere(2, radius=2.0, center=(0.0, 1.0, 0.0))
+    s = c2.create_scene(64, 48, np.array([0, 1.5, 6]), np.array([0, 0, -1]), file_specs=[dict(mesh=(v, f), material=5)],
+                        bvh_builder=builder, max_members=max_members)
+    b = s.boxes
+    leaves = b[b["right"] != 0]
+    sizes = leaves["right"] - leaves["left"]
+    assert sizes.min() >= 1 and sizes.max() <= max_members
+    covered = np.zeros(len(s.triangles), np.int32)
+    for lo, hi in zip(leaves["left"], leaves["right"]):
+        covered[lo:hi] += 1
+    assert (covered == 1).all()
+    for i in np.flatnonzero(b["right"] == 0):
+        for c in (b["left"][i], b["left"][i] + 1):
+            assert (b["min"][c][:3] >= b["min"][i][:3]).all() and (b["max"][c][:3] <= b["max"][i][:3]).all()
+    default = c2.create_scene(64, 48, np.array([0, 1.5, 6]), np.array([0, 0, -1]), file_specs=[dict(mesh=(v, f), material=5)], bvh_builder=builder)
+    assert len(default.boxes) < len(b)
+    for bad in (0, 9):
+        with pytest.raises(ValueError):
+            c2.create_scene(64, 48, np.array([0, 1.5, 6]), np.array([0, 0, -1]), bvh_builder=builder, max_members=bad)
