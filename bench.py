@@ -848,10 +848,12 @@ def main():
     ap.add_argument("--sample-streams", type=int, default=1,
                     help="sample streams of the headline workload (K independent samples of the frame per pass, cl2_set_sample_streams); "
                          "1 = the reference's single seed buffer per renderer")
-    ap.add_argument("--mesh-streams", type=int, default=8, help="sample streams of the mesh legs (their K = 1 figure is reported beside it)")
+    ap.add_argument("--mesh-streams", type=int, default=16, help="sample streams of the 1080p mesh legs (their K = 1 figure is reported beside it); round 6: 16 -- "
+                         "per-level subpath launches of 33 M rays: configs 3 / 4 / 5 6.05 -> 5.94 / 7.18 -> 6.84 / 16.7 -> 16.4 ms per sample against 8, "
+                         "24 and 32 no better (profiles/r06_sample_streams_16*.log); 3.4 KB of device memory per pixel entry: 113 GB at 16 x 1920 x 1080")
     ap.add_argument("--strong-spp", type=int, default=1024, help="N > 1: total samples of the strong-scaling leg (config 4 stand-in, split over the ranks); 0 = skip")
     ap.add_argument("--mesh-steps", type=int, default=64)
-    ap.add_argument("--hbm-steps", type=int, default=24)
+    ap.add_argument("--hbm-steps", type=int, default=32)
     ap.add_argument("--hbm4k-steps", type=int, default=8, help="samples of the config-5 leg at its own 3840 x 2160 (0 = skip)")
     ap.add_argument("--hbm4k-streams", type=int, default=2, help="sample streams of that leg (at 8.3 M pixels a launch is already large)")
     ap.add_argument("--debug-flags", type=int, default=0, help="launch-organisation switches (include/clive2_amd.h); results unchanged")

@@ -46,7 +46,7 @@ def test_committed_pmc_summaries_belong_to_the_kernel_sources_in_the_tree():
     sha = bench.kernel_sources_sha()
     newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_cornell.json")))[-1]
     tag = os.path.basename(newest).split("_")[0]
-    want = {("cornell", 1920, 1080, 1), ("glass", 1920, 1080, 8), ("blob", 1920, 1080, 8), ("interior", 1920, 1080, 8), ("interior", 3840, 2160, 2),
+    want = {("cornell", 1920, 1080, 1), ("glass", 1920, 1080, 16), ("blob", 1920, 1080, 16), ("interior", 1920, 1080, 16), ("interior", 3840, 2160, 2),
             ("glass", 1920, 1080, 1), ("blob", 1920, 1080, 1), ("interior", 1920, 1080, 1), ("interior", 3840, 2160, 1)}      # ... and the legs' one_stream forms
     have = set()
     for f in glob.glob(os.path.join(ROOT, "profiles", f"{tag}_pmc_*.json")):

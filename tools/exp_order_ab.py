@@ -25,7 +25,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def pipeline_ray_chunks(scene, samples=1, seed=0, max_chunk=1 << 22):
+def pipeline_ray_chunks(scene, samples=1, seed=0):
     """Yields (kind, origins (n,3) float32, directions (n,3) float32) for the rays of `samples` exact samples of the pipeline."""
     from clive2_amd.renderer import Renderer, make_seeds, LIGHT, CAMERA
     W, H = scene.pixel_width, scene.pixel_height
@@ -118,7 +118,6 @@ def walk_cost(scene, order, K=8, passes=3):
         r.set_counting(False)
         r.run_samples(1); r.synchronize()
         t0 = time.perf_counter(); r.run_samples(passes); r.synchronize(); dt = time.perf_counter() - t0
-        rays = r.counters()["rays"]
         r.reset_counters(); r.set_profiling(2); r.set_pipelining(0); r.run_samples(1)
         c = r.counters()
         stages = {k[3:]: round(c[k] / K, 3) for k in c if k.startswith("ms_") and c[k] > 0}

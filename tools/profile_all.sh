@@ -16,9 +16,9 @@ run() {  # scene steps pmc_steps K W H suffix
     echo "profiled $1$7"
 }
 case "${2:-all}" in
-  small) run cornell 32 4 1 1920 1080 ""; run glass 32 8 8 1920 1080 ""; run blob 32 8 8 1920 1080 "" ;;
-  interior) run interior 24 8 8 1920 1080 "" ;;
+  small) run cornell 32 4 1 1920 1080 ""; run glass 64 16 16 1920 1080 ""; run blob 64 16 16 1920 1080 "" ;;
+  interior) run interior 32 16 16 1920 1080 "" ;;
   interior4k) run interior 8 2 2 3840 2160 "_4k" ;;
   k1) run glass 32 4 1 1920 1080 "_k1"; run blob 32 4 1 1920 1080 "_k1"; run interior 16 4 1 1920 1080 "_k1"; run interior 8 2 1 3840 2160 "_4k_k1" ;;   # the legs' one_stream figures
-  all) run cornell 32 4 1 1920 1080 ""; run glass 32 8 8 1920 1080 ""; run blob 32 8 8 1920 1080 ""; run interior 24 8 8 1920 1080 ""; run interior 8 2 2 3840 2160 "_4k" ;;
+  all) run cornell 32 4 1 1920 1080 ""; run glass 64 16 16 1920 1080 ""; run blob 64 16 16 1920 1080 ""; run interior 32 16 16 1920 1080 ""; run interior 8 2 2 3840 2160 "_4k" ;;
 esac
