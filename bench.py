@@ -368,7 +368,7 @@ _SCENES = {}
 
 
 def build_scene(name, W, H, builder=None, max_members=None):
-    """(scene, description) of a bench workload; built once per process (the K = 8 and K = 1 legs share it).  `max_members`: the
+    """(scene, description) of a bench workload; built once per process (the K-stream and the one-stream leg share it).  `max_members`: the
     builder's leaf size (None = the reference's 8; anything else is a labelled experiment, never a bench leg)."""
     key = (name, W, H, builder) if max_members is None else (name, W, H, builder, max_members)
     if key not in _SCENES:
@@ -554,8 +554,8 @@ def run_workload(args, scene_name, W, H, steps, warmup, rank, local_rank, world,
                     "lane_weighted_frac": round(frac * lanes / 64.0, 4) if frac and lanes else None,
                     "wave_insts_per_launch": n_valu, "cycles_per_wave_inst": 2.0, "hbm": hbm}
         else:
-            # The tree is read through the caches.  Which resource binds the launch is decided by four fractions (mesh_roofline):
-            # vector issue, L2 request bandwidth, the level below L2, the fabric.  `own` = what the 4-wide walk itself asks for.
+            # The tree is read through the caches.  Which resource binds the launch is decided by five fractions (mesh_roofline):
+            # vector issue, the L1 look-up rate, L2 request bandwidth, the level below L2, the fabric.  `own` = what the 4-wide walk itself asks for.
             def own_bytes(tally, rays_launch):
                 if not tally or not tally["rays"]:
                     return None
