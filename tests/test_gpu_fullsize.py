@@ -403,7 +403,8 @@ def test_nearest_first_order_on_1e8_rays_of_configs_4_and_5(blob_real, interior_
     by construction -- exact-t ties between two triangles, hits a few ulp in front of their leaf box -- so its hits are COUNTED
     against the exact walk's: all subpath and connection rays of one 1920 x 1080 sample of config 4 (82k triangles) and of config 5
     (1M triangles), >= 1e8 rays in all, through the 4-wide walk in both orders.  >= 99.999 % identical (triangle, t bits); measured
-    21 of 1.7e8 (config 4, all ties) and 57 of 1.7e8 (config 5: 55 ties, 2 non-ties): profiles/r06_nearest_first_order_ab.log."""
+    47 of 3.4e8 (config 4: 45 ties, 2 non-ties) and 108 of 3.4e8 (config 5: 103 ties, 5 non-ties) over four samples:
+    profiles/r06_nearest_first_order_ab.log."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("exp_order_ab", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "exp_order_ab.py"))
     tool = importlib.util.module_from_spec(spec)

@@ -59,7 +59,7 @@ def test_traversal_order_is_opt_in(cornell_small, glass_scene, oracle_mod):
 def test_nearest_first_order_finds_the_same_hits_and_visits_less():
     """Config-3 geometry at 320 x 180, two samples of the pipeline: every subpath ray and every connection ray (rebuilt from the
     exact render's Path[]) through the 4-wide walk in both orders.  The hits agree on all but a handful of rays in 1e7 (exact-t ties;
-    measured at 1080p: 4 of 1.7e8, profiles/r06_nearest_first_order_ab.log), and the nearest-first walk visits fewer nodes."""
+    measured at 1080p: 10 of 3.4e8, profiles/r06_nearest_first_order_ab.log), and the nearest-first walk visits fewer nodes."""
     from clive2_amd.renderer import Renderer, make_seeds
     tool = _order_tool()
     scene = _glass(4, 320, 180)
