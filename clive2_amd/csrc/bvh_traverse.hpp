@@ -174,6 +174,54 @@ __device__ __forceinline__ void tri_test_branchless(V3 o, V3 d, const float4& p0
     best.v = ok ? v : best.v;
 }
 
+// tri_test_branchless for the nearest-first walk (bvh_wide.hpp, ORDER): the reference keeps the FIRST triangle it meets at a given t
+// (`t < best_t`, trace.metal:170).  A walk that meets the leaves in another order gets the same winner by letting a hit at exactly
+// best_t replace a held triangle that the reference would have met later (rank[]: position in the reference's visit order, built by
+// cl2_upload_scene; rank[-1] = INT_MIN for "nothing held" -- t = best_t = +inf, a degenerate triangle -- and one entry behind the
+// last triangle).  Ties are a few rays in 1e8: the walk tests a pair with tri_test_branchless_tie and comes here, inside a wave-level
+// branch, only when one of the two tied -- repeating a test is harmless (a triangle that holds best_t has no lower rank than itself),
+// and so is the rule where the order IS the reference's (the rays of the binary walk inside the same loop): what is held then has
+// the lower rank.
+__device__ __forceinline__ void tri_test_tie_rule(V3 o, V3 d, const float4& p0, const float4& p1, const float4& p2, int index, Hit& best,
+                                                  const int* __restrict__ rank) {
+    const V3 e1 = v3(p1), e2 = v3(p2);
+    const V3 h = cross(d, e2);
+    const float f = rcp_exact(dot(e1, h));
+    const V3 sv = o - v3(p0);
+    const float u = f * dot(sv, h);
+    const V3 q = cross(sv, e1);
+    const float v = f * dot(d, q);
+    const float t = f * dot(e2, q);
+    const bool inside = !(u < 0 || u > 1) && !(v < 0 || u + v > 1) && t > DELTA_F;
+    bool ok = inside && t < best.t;
+    if (inside && t == best.t) ok = rank[index] < rank[best.tri];
+    best.tri = ok ? index : best.tri;
+    best.t = ok ? t : best.t;
+    best.u = ok ? u : best.u;
+    best.v = ok ? v : best.v;
+}
+
+// tri_test_branchless that also says whether the triangle is hit at EXACTLY the best_t it was tested against (the nearest-first walk
+// then repeats the pair's tests under tri_test_tie_rule: one wave-level branch per pair, taken for a few rays in 1e8).
+__device__ __forceinline__ bool tri_test_branchless_tie(V3 o, V3 d, const float4& p0, const float4& p1, const float4& p2, int index, Hit& best) {
+    const V3 e1 = v3(p1), e2 = v3(p2);
+    const V3 h = cross(d, e2);
+    const float f = rcp_exact(dot(e1, h));
+    const V3 sv = o - v3(p0);
+    const float u = f * dot(sv, h);
+    const V3 q = cross(sv, e1);
+    const float v = f * dot(d, q);
+    const float t = f * dot(e2, q);
+    const bool inside = !(u < 0 || u > 1) && !(v < 0 || u + v > 1) && t > DELTA_F;
+    const bool ok = inside && t < best.t;
+    const bool tie = inside && t == best.t;
+    best.tri = ok ? index : best.tri;
+    best.t = ok ? t : best.t;
+    best.u = ok ? u : best.u;
+    best.v = ok ? v : best.v;
+    return tie;
+}
+
 // The pruned table of a tiny scene (the Cornell box: three leaves, 16 triangles) has no inner records left: every ray
 // visits record 0, 1, 2, ... in that order, whatever it hits.  The per-lane walk above then spends vector instructions on
 // bookkeeping that is the same in every lane (record index, triangle index, loop tests, LDS addresses) and waits for each

@@ -61,6 +61,7 @@ struct WideView {
     int ovf_stride;            // entries per lane: the deepest stack the uploaded tree can produce (<= WIDE_STACK_OVERFLOW)
     int stack_lds;             // stack entries kept in LDS per lane (<= WIDE_STACK_LDS)
     int n_lds_nodes;           // wide nodes [0, n_lds_nodes) (breadth-first numbering: the top of the tree) staged in LDS
+    const int* tri_rank;       // ORDER only: each triangle's position in the reference's visit order; read when two hits tie at exactly one t
 };
 
 // Round 4: the pass rewritten for its instruction count.  The ISA of round 3's loop showed what a pass paid beside its arithmetic:
@@ -113,10 +114,19 @@ struct WalkTally { unsigned visits = 0, tri_records = 0, spills = 0, bin_nodes =
 // ORDER (round 6; cl2_set_traversal_order(1), never the default and never the parity path): the passing slots of a node are taken
 // NEAREST FIRST (by entry distance, a stable 4-element network on {tmin, ref}; ties keep the reference's slot order) instead of in
 // the reference's fixed order.  A closest-hit query then finds a near hit early and prunes what lies behind it: fewer node visits
-// and triangle tests per ray.  NOT bit-exact by construction: the reference's result depends on its visit order where two
-// triangles are hit at exactly the same t (the first one visited wins, trace.metal:170) and where a hit lies a few ulp in front
-// of its own leaf box's entry distance (the leaf is then pruned or not depending on what was found before it, trace.metal:152).
-// tests/test_gpu_round6.py counts the rays whose hit differs from the exact walk's.
+// and triangle tests per ray.  What the reference's result depends on its visit order for, and what this walk does about it:
+//   * two triangles hit at exactly the same t: the first one the reference meets wins (`t < best_t`, trace.metal:170).  SETTLED the
+//     same way here: boxes are pruned on `tmin > best_t` instead of `>=` (a leaf that may hold a hit at exactly best_t is still
+//     entered), and a hit at exactly best_t replaces the held triangle when the reference would have met it first (tri_rank[]: each
+//     triangle's position in the reference's visit order, read inside a wave-level branch that is taken for a few rays in 1e8);
+//   * a hit that lies IN FRONT of its own leaf box's entry distance (rounding: a few ulp): the reference enters that leaf or not
+//     depending on the best_t it holds when it gets there (trace.metal:152), and so does any other order.  NOT reproducible in
+//     another order -- this is why the walk is not bit-exact by construction.
+// For every other ray the two walks return the same (triangle, t, u, v): let x be the first triangle in the reference's order among
+// the nearest hits of the leaves the ray's slabs enter; if t_x >= tmin of x's leaf, the reference finds x (when it gets to x's leaf it
+// holds best_t > t_x >= tmin: entered) and so does this walk (best_t >= t_x >= tmin: entered under `<=`; the tie rule keeps x).
+// tests/test_gpu_round6.py, test_gpu_fullsize.py: no differing ray is a tie, every differing ray is such a hit (2 / 3 / 5 rays of
+// 3.4e8 on configs 3 / 4 / 5).
 template <int TRI_REPS, bool TALLY, bool SPEC, bool PACK, bool ORDER, class Source>
 __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, const BvhView& b, unsigned n, unsigned* work_counter, const Source& src, WalkTally& tally) {
     constexpr bool TWO_TRIS = true;
@@ -160,7 +170,7 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
                 int ref, tbits;
                 if (sp < WIDE_S) { const int2 e = s_stack[sp * NT]; ref = e.x; tbits = e.y; }
                 else { ref = ovf[2 * (sp - WIDE_S)]; tbits = ovf[2 * (sp - WIDE_S) + 1]; }
-                if (__int_as_float(tbits) < best.t) { take(ref); need = false; }
+                if (ORDER ? __int_as_float(tbits) <= best.t : __int_as_float(tbits) < best.t) { take(ref); need = false; }
                 else need = sp > 0;
             }
         }
@@ -237,7 +247,7 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
                 const int2 e = s_stack[(sp - 1) * NT];
                 if (e.x >= 0) {                                             // a wide node on top: it leaves the stack, pruned or expanded
                     sp--;
-                    spec = __int_as_float(e.y) < best.t;
+                    spec = ORDER ? __int_as_float(e.y) <= best.t : __int_as_float(e.y) < best.t;
                     spec_ref = e.x;
                 }
             }
@@ -288,7 +298,9 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
                                                        __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
                     const float tmax = __builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fminf(__builtin_fmaxf(t0y, t1y), __builtin_fmaxf(t0z, t1z)));
                     tm[k] = tmin;
-                    pass[k] = tmin <= tmax && tmin < best.t;                // an empty slot's box lies at +inf: never
+                    // an empty slot's box lies at +inf: never.  (ORDER: `<=`, so that a leaf that may hold a hit at exactly best_t is still
+                    // entered -- the tie rule then decides as the reference does; an empty slot goes by its reference, below)
+                    pass[k] = tmin <= tmax && (ORDER ? tmin <= best.t : tmin < best.t);
                 }
                 if (ORDER) {
                     // nearest first: slots that do not pass sort behind all that do (key +inf, no reference); adjacent
@@ -365,18 +377,46 @@ __device__ __forceinline__ void traverse_wide_persistent(const WideView& w, cons
                     float a[18];
 #pragma unroll
                     for (int k = 0; k < 18; k++) a[k] = ta[k];
-                    tri_test_branchless(o, d, make_float4(a[0], a[1], a[2], 0.0f), make_float4(a[3], a[4], a[5], 0.0f), make_float4(a[6], a[7], a[8], 0.0f), i0, best);
-                    Hit second = best;
-                    tri_test_branchless(o, d, make_float4(a[9], a[10], a[11], 0.0f), make_float4(a[12], a[13], a[14], 0.0f), make_float4(a[15], a[16], a[17], 0.0f), i0 + 1, second);
-                    if (i1 != i0) best = second;
+                    if (ORDER) {
+                        bool tie = tri_test_branchless_tie(o, d, make_float4(a[0], a[1], a[2], 0.0f), make_float4(a[3], a[4], a[5], 0.0f), make_float4(a[6], a[7], a[8], 0.0f), i0, best);
+                        Hit second = best;
+                        const bool tie2 = tri_test_branchless_tie(o, d, make_float4(a[9], a[10], a[11], 0.0f), make_float4(a[12], a[13], a[14], 0.0f), make_float4(a[15], a[16], a[17], 0.0f), i0 + 1, second);
+                        if (i1 != i0) { best = second; tie = tie || tie2; }
+                        if (__any(tie)) {
+                            // a hit at exactly best_t: the pair again, under the reference's rule for ties (whatever the strict tests kept
+                            // holds the same best_t: the repeated tests can only exchange triangles that tie at it)
+                            if (tie) {
+                                const float* __restrict__ tr = w.tris36 + (size_t)9 * i0;
+                                tri_test_tie_rule(o, d, make_float4(tr[0], tr[1], tr[2], 0.0f), make_float4(tr[3], tr[4], tr[5], 0.0f), make_float4(tr[6], tr[7], tr[8], 0.0f), i0, best, w.tri_rank);
+                                if (i1 != i0)
+                                    tri_test_tie_rule(o, d, make_float4(tr[9], tr[10], tr[11], 0.0f), make_float4(tr[12], tr[13], tr[14], 0.0f), make_float4(tr[15], tr[16], tr[17], 0.0f), i1, best, w.tri_rank);
+                            }
+                        }
+                    } else {
+                        tri_test_branchless(o, d, make_float4(a[0], a[1], a[2], 0.0f), make_float4(a[3], a[4], a[5], 0.0f), make_float4(a[6], a[7], a[8], 0.0f), i0, best);
+                        Hit second = best;
+                        tri_test_branchless(o, d, make_float4(a[9], a[10], a[11], 0.0f), make_float4(a[12], a[13], a[14], 0.0f), make_float4(a[15], a[16], a[17], 0.0f), i0 + 1, second);
+                        if (i1 != i0) best = second;
+                    }
                 } else {
                     const float4* __restrict__ ta = w.tris + (size_t)3 * i0;
                     const float4* __restrict__ tb = w.tris + (size_t)3 * i1;
                     const float4 a0 = ta[0], a1 = ta[1], a2 = ta[2];
                     float4 c0, c1, c2;
                     if (TWO_TRIS) { c0 = tb[0]; c1 = tb[1]; c2 = tb[2]; }
-                    tri_test_branchless(o, d, a0, a1, a2, i0, best);
-                    if (TWO_TRIS) tri_test_branchless(o, d, c0, c1, c2, i1, best);
+                    if (ORDER) {
+                        bool tie = tri_test_branchless_tie(o, d, a0, a1, a2, i0, best);
+                        if (TWO_TRIS) tie = (tri_test_branchless_tie(o, d, c0, c1, c2, i1, best) && i1 != i0) || tie;   // (an odd leaf's last triangle is tested twice: no tie)
+                        if (__any(tie)) {
+                            if (tie) {
+                                tri_test_tie_rule(o, d, ta[0], ta[1], ta[2], i0, best, w.tri_rank);
+                                if (TWO_TRIS) tri_test_tie_rule(o, d, tb[0], tb[1], tb[2], i1, best, w.tri_rank);
+                            }
+                        }
+                    } else {
+                        tri_test_branchless(o, d, a0, a1, a2, i0, best);
+                        if (TWO_TRIS) tri_test_branchless(o, d, c0, c1, c2, i1, best);
+                    }
                 }
             }
         }

@@ -85,6 +85,7 @@ struct cl2_renderer {
     // 4-wide collapse of the tree for the exact wide walk (bvh_wide.hpp); n_wide == 0: not available for this scene
     float4* d_wide = nullptr;
     int n_wide = 0;
+    int* d_tri_rank = nullptr;           // ORDER: each triangle's position in the reference's visit order (exact-t ties; bvh_wide.hpp)
     float* d_tris36 = nullptr;           // 36-byte triangle records of a tree that streams from beyond L2 (bvh_wide.hpp, PACK); nullptr: none
     int n_fast = 0;                      // records of the pruned table (bvh.n_fast_nodes unless debug_flags bit 7 switches it off)
     CamTris cam_tris{0, {0, 0, 0, 0}};   // the triangles with is_camera set, as kernel arguments of the resolve stage (n < 0: too many, look them up)
@@ -1153,6 +1154,8 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
     dev_free(r, r->d_wide);
     dev_free(r, r->d_tris36);
     r->wide.tris36 = nullptr;
+    dev_free(r, r->d_tri_rank);
+    r->wide.tri_rank = nullptr;
     r->n_wide = 0;
     if (n_wide > 0) {
         // the wide walk reads the triangle records without their three padding words (36 bytes each; bvh_wide.hpp, PACK)
@@ -1177,6 +1180,24 @@ int cl2_upload_scene(cl2_renderer* r, const void* boxes_v, int n_boxes, const vo
         r->wide.nodes = r->d_wide; r->wide.tris = r->d_tris;
         r->wide.root_lo = make_float4(boxes[0].min[0], boxes[0].min[1], boxes[0].min[2], 0.0f);
         r->wide.root_hi = make_float4(boxes[0].max[0], boxes[0].max[1], boxes[0].max[2], 0.0f);
+        // The nearest-first walk (ORDER) settles exact-t ties the way the reference does -- the triangle it meets FIRST wins,
+        // trace.metal:170 -- from each triangle's position in the reference's visit order (child left+1 first, a leaf's triangles in
+        // index order).  np_flatten_bvh numbers leaves breadth-first, so the index alone does not say it.  Read on ties only.
+        {
+            // [0]: "nothing held" (best.tri = -1) ranks before everything; [1 + t]: triangle t; [1 + n_tris]: behind the last triangle
+            std::vector<int> h_rank((size_t)n_tris + 2, 0x7fffffff), st{0};
+            h_rank[0] = (int)0x80000000;
+            int next_rank = 0;
+            while (!st.empty()) {
+                const int x = st.back(); st.pop_back();
+                const BoxRec& bx = boxes[x];
+                if (bx.right == 0) { st.push_back(bx.left); st.push_back(bx.left + 1); continue; }   // left+1 on top: popped first
+                for (int t = bx.left; t < bx.right; t++) if (h_rank[1 + (size_t)t] == 0x7fffffff) h_rank[1 + (size_t)t] = next_rank++;
+            }
+            TRY(dev_alloc(r, &r->d_tri_rank, h_rank.size()));
+            HIP_TRY(r, hipMemcpy(r->d_tri_rank, h_rank.data(), h_rank.size() * sizeof(int), hipMemcpyHostToDevice));
+            r->wide.tri_rank = r->d_tri_rank + 1;
+        }
         r->n_wide = n_wide;
     }
     r->bvh.nodes = r->d_nodes; r->bvh.tris = r->d_tris;

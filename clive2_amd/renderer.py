@@ -354,8 +354,9 @@ class Renderer:
 
     def set_traversal_order(self, order=1):
         """Child order of the 4-wide walks (cl2_set_traversal_order): 0 = the reference's fixed order (trace.metal:157-160; the
-        default, bit-exact), 1 = nearest child first -- fewer node visits and triangle tests per ray, NOT bit-exact by
-        construction (exact-t ties, hits a few ulp in front of their leaf box).  Opt-in; no reference counterpart."""
+        default, bit-exact), 1 = nearest child first -- fewer node visits and triangle tests per ray; exact-t ties go to the triangle
+        the reference meets first, but NOT bit-exact by construction (a hit that rounding puts in front of its own leaf box is found
+        or not depending on the visit order: a few rays in 1e8).  Opt-in; no reference counterpart."""
         self._check(self._L.cl2_set_traversal_order(self._h, int(order)), "set_traversal_order")
 
     def traversal_order(self):

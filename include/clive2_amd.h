@@ -310,9 +310,11 @@ int cl2_get_reproducible(const cl2_renderer* r);
  * whatever the ray (src/trace.metal:157-160) -- which is what makes every output byte-comparable with the reference's.  order = 1:
  * the passing children of a node are taken NEAREST FIRST (by slab entry distance).  A closest-hit query then prunes what lies behind
  * its first hit: fewer node visits and triangle tests per ray.  NOT the reference's result by construction -- the reference's hit
- * depends on its visit order where two triangles are hit at exactly the same t (first visited wins, trace.metal:170) and where a hit
- * lies a few ulp in front of its leaf box's entry distance (trace.metal:152) -- so: opt-in, never the default, never the parity path;
- * bench.py's headline and every parity test run with 0, and tests/test_gpu_round6.py counts the rays whose hit differs.  Applies to
+ * depends on its visit order where a hit lies a few ulp in front of its own leaf box's entry distance (the leaf is entered or not
+ * depending on what was found before it, trace.metal:152); two triangles hit at exactly the same t (first visited wins,
+ * trace.metal:170) ARE settled as the reference settles them (a table of each triangle's position in its visit order) -- so: opt-in,
+ * never the default, never the parity path; bench.py's headline and every parity test run with 0, and tests/test_gpu_round6.py /
+ * test_gpu_fullsize.py count the rays whose hit differs (2 to 5 in 3.4e8) and check that each is such a hit.  Applies to
  * scenes whose tree is read through the caches (the 4-wide walk; an LDS-resident tree such as the Cornell box renders the same
  * either way).  No reference counterpart (src/trace.metal:144-176 has one order). */
 int cl2_set_traversal_order(cl2_renderer* r, int order);

@@ -61,12 +61,28 @@ def pipeline_ray_chunks(scene, samples=1, seed=0):
         r.close()
 
 
+def leaf_entry_distance(scene, tri, o, d):
+    """tmin of the slab test (trace.metal:150-156, the kernel's own float32 operations) of the LEAF box that holds triangle `tri`."""
+    b = scene.boxes
+    leaf = np.nonzero((b["right"] != 0) & (b["left"] <= tri) & (tri < b["right"]))[0]
+    assert len(leaf) == 1, (tri, leaf)
+    lo, hi = b["min"][leaf[0], :3].astype(np.float32), b["max"][leaf[0], :3].astype(np.float32)
+    o, d = np.asarray(o, np.float32), np.asarray(d, np.float32)
+    with np.errstate(divide="ignore"):
+        inv = (np.float32(1.0) / d).astype(np.float32)
+    t0, t1 = ((lo - o) * inv).astype(np.float32), ((hi - o) * inv).astype(np.float32)
+    return float(max(np.minimum(t0, t1).max(), np.float32(0.0)))
+
+
 def compare_orders(scene, chunks, log=None):
-    """Sends every chunk through the 4-wide walk in both orders; returns the tallies of (i)."""
+    """Sends every chunk through the 4-wide walk in both orders; returns the tallies of (i).  Every difference is explained:
+    `in_front_of_own_leaf` counts the differing rays on which one of the two reported hits lies in front of its own leaf box's entry
+    distance -- the one case in which the reference's result depends on its visit order (bvh_wide.hpp, ORDER); it must equal `differ`."""
     from clive2_amd import struct_types as st
     from clive2_amd.renderer import Renderer
     r0, r1 = Renderer(scene), Renderer(scene)
-    out = {"rays": 0, "differ": 0, "ties": 0, "non_ties": 0, "missed_by_order1": 0, "missed_by_order0": 0, "by_kind": {}, "examples": []}
+    out = {"rays": 0, "differ": 0, "ties": 0, "non_ties": 0, "in_front_of_own_leaf": 0, "missed_by_order1": 0, "missed_by_order0": 0, "by_kind": {},
+           "examples": []}
     try:
         for r, order in ((r0, 0), (r1, 1)):
             r.set_traversal_mode(5)
@@ -94,9 +110,16 @@ def compare_orders(scene, chunks, log=None):
                 out["ties"] += int(tie.sum()); out["non_ties"] += int((~tie).sum())
                 out["missed_by_order1"] += int(((i1[idx] < 0) & (i0[idx] >= 0)).sum())
                 out["missed_by_order0"] += int(((i0[idx] < 0) & (i1[idx] >= 0)).sum())
-                for j in idx[:max(0, 8 - len(out["examples"]))]:
-                    out["examples"].append({"kind": kind, "tri": [int(i0[j]), int(i1[j])], "t": [float(t0[j]), float(t1[j])],
-                                            "t_bits": ["%08x" % tb0[j], "%08x" % tb1[j]]})
+                for j in idx:
+                    # the hit of either walk that lies in front of its own leaf box's entry distance (the one case in which a result
+                    # depends on the visit order); a tie that survives the tie rule is such a hit too: the leaf of the triangle the
+                    # reference met first is not entered once the other triangle is held at the same t
+                    entry = [leaf_entry_distance(scene, int(i), o[j], d[j]) if i >= 0 else None for i in (i0[j], i1[j])]
+                    front = [e is not None and float(t) < e for e, t in zip(entry, (t0[j], t1[j]))]
+                    out["in_front_of_own_leaf"] += int(any(front))
+                    if len(out["examples"]) < 32:
+                        out["examples"].append({"kind": kind, "tie": bool(tb0[j] == tb1[j]), "tri": [int(i0[j]), int(i1[j])], "t": [float(t0[j]), float(t1[j])],
+                                                "t_bits": ["%08x" % tb0[j], "%08x" % tb1[j]], "leaf_entry": entry, "in_front": front})
             if log:
                 log(f"  {kind:10s} {n:9d} rays  differ {nd}")
     finally:
