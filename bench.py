@@ -645,7 +645,7 @@ def mesh_leg(args, key, name, W, H, n_steps, streams, local_rank):
             # a labelled extra, never the leg's figure: the same workload with the opt-in nearest-first child order of the 4-wide walks
             # (cl2_set_traversal_order(1): NOT bit-exact by construction -- tests/test_gpu_fullsize.py counts the rays whose hit differs)
             mo = run_workload(args, name, W, H, max(streams, n_steps // 2), 2, 0, local_rank, 1, with_comm=False, streams=streams, order=1)
-            leg["nearest_first_extra"] = {"label": "opt-in cl2_set_traversal_order(1): nearest child first, NOT bit-exact (exact-t ties); not the leg's figure",
+            leg["nearest_first_extra"] = {"label": "opt-in cl2_set_traversal_order(1): nearest child first, NOT bit-exact (a hit that rounding puts in front of its own leaf box; exact-t ties go the reference's way); not the leg's figure",
                                           "mrays_per_s": round(mo["rays_total"] / mo["dt"] / 1e6, 2), "ms_per_step": round(mo["dt"] / mo["steps_rank"] * 1e3, 3),
                                           "sample_streams": streams, "steps": mo["steps_rank"]}
     except Exception as exc:                                   # noqa: BLE001
