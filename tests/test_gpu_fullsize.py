@@ -405,7 +405,8 @@ def test_nearest_first_order_on_1e8_rays_of_configs_4_and_5(blob_real, interior_
     (82k triangles) and of config 5 (1M triangles), >= 1e8 rays in all, through the 4-wide walk in both orders.  >= 99.999 %
     identical (triangle, t bits).  Exact-t ties between two triangles are settled as the reference settles them (rank table): NO
     difference may be a tie, and every difference must be explained by a hit in front of its own leaf box (measured over four
-    samples: 3 of 3.4e8 on config 4, 5 of 3.4e8 on config 5; without the tie rule 48 and 108): profiles/r06_nearest_first_order_ab.log."""
+    samples: 3 of 3.4e8 on config 4, 9 of 3.4e8 on config 5 -- 4 of the 9 at the same t bits: the leaf of the triangle the reference met
+    first is not entered once the other is held; without the tie rule 48 and 108): profiles/r06_nearest_first_order_ab.log."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("exp_order_ab", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "exp_order_ab.py"))
     tool = importlib.util.module_from_spec(spec)
